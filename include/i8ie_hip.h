@@ -1,0 +1,157 @@
+/*
+ * i8ie_hip.h -- C-ABI of libi8ie_hip.so: the MI355X (gfx950) implementation of
+ * the INT8 hot path of t0037799/INT8InferenceEngine.
+ *
+ * This is the boundary the rebuilt pybind11 module `_CXX_i8ie` (and any other
+ * FFI: ctypes, cgo, JNI) binds.  Plain pointers and sizes only; no C++ types,
+ * no torch types, no exceptions cross it.  Every entry point cites the
+ * reference interface it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - every function returns an int status: I8IE_OK (0) or a negative code;
+ *     i8ie_last_error() returns a thread-local message for the last failure.
+ *     (The reference throws message-less std::exception or segfaults on
+ *     misuse: include/tensor.h:114-130, src/conv2d.cc:105.)
+ *   - "dev" pointers are device (HBM) pointers, obtained from i8ie_malloc or
+ *     from any other HIP allocation in the same process (e.g. a torch tensor's
+ *     data_ptr()).  Ops enqueue on the ctx's HIP stream and return without
+ *     waiting; i8ie_sync() or a D2H copy waits.
+ *   - tensors use the reference's layouts: activations u8 NCHW / [m,k]
+ *     row-major, weights s8 [out, in*kh*kw] row-major (K ordered c,kh,kw),
+ *     per-tensor fp32 scale + u8 zero point (include/tensor.h:152-154).
+ *   - arithmetic is the reference's, bit for bit: exact int32 accumulation,
+ *     fp32 epilogue without contraction or reassociation.
+ */
+#ifndef I8IE_HIP_H
+#define I8IE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I8IE_OK 0
+#define I8IE_ERR_ARG (-1)   /* bad argument (null pointer, non-positive size, stride 0 ...) */
+#define I8IE_ERR_STATE (-2) /* call made in the wrong state (e.g. forward before qparams set) */
+#define I8IE_ERR_HIP (-3)   /* a HIP runtime call failed; message has hipGetErrorString */
+#define I8IE_ERR_OOM (-4)   /* device allocation failed */
+
+typedef struct i8ie_ctx i8ie_ctx;     /* one per (thread-of-control, device): stream + workspace */
+typedef struct i8ie_layer i8ie_layer; /* a converted (INT8) Linear or Conv2d with device-resident weights */
+
+/* ---- library / context ------------------------------------------------- */
+const char* i8ie_last_error(void);
+int i8ie_version(void);                 /* ABI version, currently 1 */
+int i8ie_device_count(int* n);
+int i8ie_ctx_create(int device, i8ie_ctx** out);                       /* own stream */
+int i8ie_ctx_create_on_stream(int device, void* hip_stream, i8ie_ctx** out); /* borrow a hipStream_t */
+int i8ie_ctx_destroy(i8ie_ctx* ctx);
+void* i8ie_ctx_stream(i8ie_ctx* ctx);   /* the hipStream_t, as void* */
+int i8ie_sync(i8ie_ctx* ctx);
+
+/* ---- device memory (replaces `new T[]` + py::capsule, include/tensor.h:26-61) */
+/* Blocks come from a per-ctx caching allocator: i8ie_free() never blocks, and a freed
+ * block may be handed to the next i8ie_malloc() at once.  That is safe because every
+ * consumer of ctx memory runs on the ctx's stream; do not read a block from another
+ * stream after freeing it.  i8ie_trim() returns cached blocks to the driver. */
+int i8ie_malloc(i8ie_ctx* ctx, size_t bytes, void** dev);
+int i8ie_free(i8ie_ctx* ctx, void* dev);
+int i8ie_trim(i8ie_ctx* ctx);
+int i8ie_memory_stats(i8ie_ctx* ctx, size_t* bytes_live, size_t* bytes_cached, size_t* n_device_allocs);
+int i8ie_memcpy_h2d(i8ie_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int i8ie_memcpy_d2h(i8ie_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* waits */
+int i8ie_memcpy_d2d(i8ie_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
+int i8ie_memset(i8ie_ctx* ctx, void* dst_dev, int byte, size_t bytes);
+
+/* ---- elementwise ops ---------------------------------------------------- */
+/* quantize(Tensor<float>&, scale, zp)  src/quantize_utils.cc:44-52, src/pybind11.cc:41-45
+ * q = (u8)(x / scale + zp): fp32 divide, add, truncate, low 8 bits (no clamp). */
+int i8ie_quantize_f32_u8(i8ie_ctx* ctx, const float* in_dev, uint8_t* out_dev, int64_t n,
+                         float scale, uint8_t zero_point);
+/* dequantize(Tensor<u8>&)  src/quantize_utils.cc:38-42,54-58, src/pybind11.cc:46-48 */
+int i8ie_dequantize_u8_f32(i8ie_ctx* ctx, const uint8_t* in_dev, float* out_dev, int64_t n,
+                           float scale, uint8_t zero_point);
+/* relu<u8_t>  src/functional.cc:15-26:  out = in > zp ? in : zp */
+int i8ie_relu_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int64_t n,
+                 uint8_t zero_point);
+/* max_pool2d<u8_t>  src/functional.cc:36-64: NCHW, k x k window, stride s, floor, no padding */
+int i8ie_maxpool2d_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int n, int c,
+                      int h, int w, int kernel_size, int stride);
+/* down_scale  src/quantize_utils.cc:27-36 (standalone requantiser; the layers fuse it) */
+int i8ie_down_scale(i8ie_ctx* ctx, const int32_t* acc_dev, uint8_t* out_dev, int64_t n, float sa,
+                    float sb, float sc, uint8_t zp_c);
+
+/* ---- FP32 ops: the path taken before convert() and while calibrating -------
+ * Conv2d/Linear::forward_prop(Tensor<float>&&)  src/conv2d.cc:63-98, src/fully_connected.cc:5-21
+ * (cblas_sgemm + bias); relu<float>, max_pool2d<float>  src/functional.cc:5-13,36-64.
+ * Off the timed INT8 path: plain correct kernels, pinned to the reference's own
+ * tolerance (atol 0.1 vs torch, unittest/test_layers.py:10-11). */
+int i8ie_linear_f32(i8ie_ctx* ctx, const float* in_dev, int m, int k, const float* w_dev,
+                    const float* b_dev, int n, float* out_dev);
+int i8ie_conv2d_f32(i8ie_ctx* ctx, const float* in_dev, int n, int c, int h, int w,
+                    const float* w_dev, const float* b_dev, int kc, int kh, int kw, int stride,
+                    int pad, float* out_dev);
+int i8ie_relu_f32(i8ie_ctx* ctx, const float* in_dev, float* out_dev, int64_t n);
+int i8ie_maxpool2d_f32(i8ie_ctx* ctx, const float* in_dev, float* out_dev, int n, int c, int h,
+                       int w, int kernel_size, int stride);
+
+/* ---- weight preparation (host side, one-shot) --------------------------- */
+/* quantize_weight  src/layer.cc:6-26: joint min/max over weight and bias,
+ * s_w = (max - min) / 127, q = (s8)(x / s_w) truncating, unclamped.  Host pointers. */
+int i8ie_quantize_weight(const float* w_host, int64_t nw, const float* b_host, int64_t nb,
+                         int8_t* qw_host, int8_t* qb_host, float* scale_out);
+
+/* ---- zero-point offset vectors (device) --------------------------------- */
+/* src/conv2d.cc:117-124:  t_j = sum_k zp_in*q_w[j,k] accumulated sequentially in fp32;
+ * oc[j] = (int)((float)q_b[j] / s_in - t_j).  qw_dev: s8 [kc, K]; oc_dev: int32 [kc]. */
+int i8ie_conv_offsets(i8ie_ctx* ctx, const int8_t* qw_dev, const int8_t* qb_dev, int kc, int K,
+                      float s_in, uint8_t zp_in, int32_t* oc_dev);
+/* src/fully_connected.cc:30-38:  oc[i] = (int)(-t_i) */
+int i8ie_linear_offsets(i8ie_ctx* ctx, const int8_t* qw_dev, int n, int k, uint8_t zp_in,
+                        int32_t* oc_dev);
+
+/* ---- stateless layer entry points (raw device pointers) ------------------ */
+/* Linear::forward_prop(Tensor<u8>&&)  src/fully_connected.cc:22-52
+ *   C = X*W^T + oc (exact int32);  C = (int)((float)C + (float)q_b[j]/s_in);
+ *   out = down_scale(C, s_in, s_w, s_out, zp_out).
+ * in [m,k] u8, qw [n,k] s8, qb [n] s8, oc [n] int32 (from i8ie_linear_offsets), out [m,n] u8.
+ * acc_dbg_dev: NULL, or int32 [m,n] receiving C BEFORE the float bias step (the
+ * MKL cblas_gemm_s8u8s32 result, src/fully_connected.cc:39-41).               */
+int i8ie_linear_u8s8(i8ie_ctx* ctx, const uint8_t* in_dev, int m, int k, const int8_t* qw_dev,
+                     const int8_t* qb_dev, int n, const int32_t* oc_dev, float s_in, float s_w,
+                     float s_out, uint8_t zp_out, uint8_t* out_dev, int32_t* acc_dbg_dev);
+/* Conv2d::forward_prop(Tensor<u8>&&)  src/conv2d.cc:100-142
+ *   per image: im2col (pad value zp_in) -> C = A*W^T + oc -> down_scale -> HWC->CHW.
+ * in NCHW [n,c,h,w] u8, qw [kc, c*kh*kw] s8, oc [kc] int32 (from i8ie_conv_offsets),
+ * out NCHW [n,kc,oh,ow] u8, oh = (h - kh + 2*pad)/stride + 1.
+ * acc_dbg_dev: NULL, or int32 [n, oh*ow, kc]: the pre-requant accumulators
+ * (the MKL result, src/conv2d.cc:131-133).                                   */
+int i8ie_conv2d_u8s8(i8ie_ctx* ctx, const uint8_t* in_dev, int n, int c, int h, int w,
+                     const int8_t* qw_dev, int kc, int kh, int kw, int stride, int pad,
+                     uint8_t zp_in, const int32_t* oc_dev, float s_in, float s_w, float s_out,
+                     uint8_t zp_out, uint8_t* out_dev, int32_t* acc_dbg_dev);
+
+/* ---- layer handles: converted layers with device-resident packed weights -
+ * What BaseLayer::convert() leaves behind (src/layer.cc:36-54: q_weight_,
+ * q_bias_, scale_, zero_point_), kept on the device in MFMA operand order,
+ * plus the offset vector cached per (s_in, zp_in) instead of being recomputed
+ * on every call (src/conv2d.cc:117-124).                                     */
+int i8ie_linear_create(i8ie_ctx* ctx, const int8_t* qw_host, const int8_t* qb_host, int n, int k,
+                       float s_w, i8ie_layer** out);
+int i8ie_conv2d_create(i8ie_ctx* ctx, const int8_t* qw_host, const int8_t* qb_host, int kc, int c,
+                       int kh, int kw, int stride, int pad, float s_w, i8ie_layer** out);
+/* the layer's output (scale_, zero_point_): src/layer.cc:44, include/layer.h:46-47 (default 1, 0) */
+int i8ie_layer_set_output_qparams(i8ie_layer* layer, float s_out, uint8_t zp_out);
+int i8ie_layer_get_output_qparams(const i8ie_layer* layer, float* s_out, uint8_t* zp_out);
+/* Linear: in [m,k] -> out [m,n].  Conv2d: in NCHW [m,c,h,w] (m = batch) -> out NCHW.
+ * h, w are ignored for Linear.  acc_dbg_dev as in the stateless calls.       */
+int i8ie_layer_forward(i8ie_layer* layer, const uint8_t* in_dev, int m, int h, int w, float s_in,
+                       uint8_t zp_in, uint8_t* out_dev, int32_t* acc_dbg_dev);
+int i8ie_layer_destroy(i8ie_layer* layer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I8IE_HIP_H */

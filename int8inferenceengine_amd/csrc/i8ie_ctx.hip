@@ -1,0 +1,244 @@
+// i8ie_ctx.hip -- context, errors, device memory of libi8ie_hip.so.
+// Replaces the reference's host-side `new T[]` + py::capsule ownership
+// (include/tensor.h:26-61) with explicit device allocations on one HIP stream.
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <unordered_map>
+
+#include "i8ie_internal.h"
+
+// Stream-ordered caching allocator.  Every consumer of a block (kernels, copies)
+// runs on the ctx's one stream, so a block handed back by the host can be given
+// to a later op at once: that op is queued behind everything that still reads
+// the block.  Avoids a hipStreamSynchronize + hipFree each time the Python side
+// drops an intermediate tensor in the middle of a forward pass.
+struct I8iePool {
+  std::multimap<size_t, void*> free_blocks;      // size -> block
+  std::unordered_map<void*, size_t> live;        // block -> size
+  size_t bytes_live = 0, bytes_cached = 0, n_hip_malloc = 0;
+};
+static inline I8iePool* pool_of(i8ie_ctx* c) { return static_cast<I8iePool*>(c->pool); }
+static inline size_t pool_round(size_t b) {
+  if (b < 256) b = 256;
+  if (b <= ((size_t)1 << 20)) return i8ie_align_up(b, 256);
+  return i8ie_align_up(b, (size_t)1 << 20);
+}
+static void pool_trim(i8ie_ctx* c) {
+  I8iePool* p = pool_of(c);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kv : p->free_blocks) (void)hipFree(kv.second);
+  p->free_blocks.clear();
+  p->bytes_cached = 0;
+}
+
+static thread_local char g_err[512] = "";
+
+void i8ie_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+const char* i8ie_last_error(void) { return g_err; }
+int i8ie_version(void) { return 1; }
+
+int i8ie_device_count(int* n) {
+  I8IE_REQUIRE(n != nullptr, "null output");
+  I8IE_HIP_TRY(hipGetDeviceCount(n));
+  return I8IE_OK;
+}
+
+static int ctx_make(int device, hipStream_t borrowed, bool borrow, i8ie_ctx** out) {
+  I8IE_REQUIRE(out != nullptr, "null output");
+  int ndev = 0;
+  I8IE_HIP_TRY(hipGetDeviceCount(&ndev));
+  I8IE_REQUIRE(device >= 0 && device < ndev, "no such device");
+  I8IE_HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  I8IE_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    i8ie_set_error("i8ie_ctx_create: device %d is %s; this library is built for gfx950 only", device,
+                   prop.gcnArchName);
+    return I8IE_ERR_STATE;
+  }
+  i8ie_ctx* c = new (std::nothrow) i8ie_ctx();
+  if (!c) return I8IE_ERR_OOM;
+  c->pool = new (std::nothrow) I8iePool();
+  if (!c->pool) {
+    delete c;
+    return I8IE_ERR_OOM;
+  }
+  c->device = device;
+  if (borrow) {
+    c->stream = borrowed;
+    c->own_stream = false;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      i8ie_set_error("hipStreamCreate: %s", hipGetErrorString(e));
+      delete pool_of(c);
+      delete c;
+      return I8IE_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  *out = c;
+  return I8IE_OK;
+}
+
+int i8ie_ctx_create(int device, i8ie_ctx** out) { return ctx_make(device, nullptr, false, out); }
+int i8ie_ctx_create_on_stream(int device, void* hip_stream, i8ie_ctx** out) {
+  return ctx_make(device, (hipStream_t)hip_stream, true, out);
+}
+
+int i8ie_ctx_destroy(i8ie_ctx* ctx) {
+  if (!ctx) return I8IE_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  pool_trim(ctx);
+  for (auto& kv : pool_of(ctx)->live) (void)hipFree(kv.first);  // leaked by the caller
+  delete pool_of(ctx);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return I8IE_OK;
+}
+
+void* i8ie_ctx_stream(i8ie_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int i8ie_sync(i8ie_ctx* ctx) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return I8IE_OK;
+}
+
+int i8ie_malloc(i8ie_ctx* ctx, size_t bytes, void** dev) {
+  I8IE_REQUIRE(ctx != nullptr && dev != nullptr, "null argument");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  *dev = nullptr;
+  I8iePool* p = pool_of(ctx);
+  const size_t want = pool_round(bytes);
+  auto it = p->free_blocks.lower_bound(want);
+  if (it != p->free_blocks.end() && it->first <= want + want / 4) {
+    *dev = it->second;
+    p->bytes_cached -= it->first;
+    p->live[*dev] = it->first;
+    p->bytes_live += it->first;
+    p->free_blocks.erase(it);
+    return I8IE_OK;
+  }
+  hipError_t e = hipMalloc(dev, want);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    pool_trim(ctx);  // give cached blocks back and retry once
+    e = hipMalloc(dev, want);
+  }
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    *dev = nullptr;
+    i8ie_set_error("i8ie_malloc: out of device memory (%zu bytes)", bytes);
+    return I8IE_ERR_OOM;
+  }
+  I8IE_HIP_TRY(e);
+  p->n_hip_malloc++;
+  p->live[*dev] = want;
+  p->bytes_live += want;
+  return I8IE_OK;
+}
+
+int i8ie_free(i8ie_ctx* ctx, void* dev) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  if (!dev) return I8IE_OK;
+  I8iePool* p = pool_of(ctx);
+  auto it = p->live.find(dev);
+  I8IE_REQUIRE(it != p->live.end(), "pointer was not allocated by i8ie_malloc on this ctx");
+  const size_t sz = it->second;
+  p->live.erase(it);
+  p->bytes_live -= sz;
+  p->free_blocks.emplace(sz, dev);  // no sync: reuse is ordered by the ctx's stream
+  p->bytes_cached += sz;
+  return I8IE_OK;
+}
+
+int i8ie_trim(i8ie_ctx* ctx) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  pool_trim(ctx);
+  return I8IE_OK;
+}
+
+int i8ie_memory_stats(i8ie_ctx* ctx, size_t* bytes_live, size_t* bytes_cached, size_t* n_device_allocs) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  I8iePool* p = pool_of(ctx);
+  if (bytes_live) *bytes_live = p->bytes_live;
+  if (bytes_cached) *bytes_cached = p->bytes_cached + ctx->ws_bytes;
+  if (n_device_allocs) *n_device_allocs = p->n_hip_malloc;
+  return I8IE_OK;
+}
+
+int i8ie_memcpy_h2d(i8ie_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  if (bytes == 0) return I8IE_OK;
+  I8IE_REQUIRE(dst_dev != nullptr && src_host != nullptr, "null pointer");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8IE_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // the host buffer may be pageable and freed by the caller right after return
+  I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return I8IE_OK;
+}
+
+int i8ie_memcpy_d2h(i8ie_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  if (bytes == 0) return I8IE_OK;
+  I8IE_REQUIRE(dst_host != nullptr && src_dev != nullptr, "null pointer");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8IE_HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return I8IE_OK;
+}
+
+int i8ie_memcpy_d2d(i8ie_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  if (bytes == 0) return I8IE_OK;
+  I8IE_REQUIRE(dst_dev != nullptr && src_dev != nullptr, "null pointer");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8IE_HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return I8IE_OK;
+}
+
+int i8ie_memset(i8ie_ctx* ctx, void* dst_dev, int byte, size_t bytes) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  if (bytes == 0) return I8IE_OK;
+  I8IE_REQUIRE(dst_dev != nullptr, "null pointer");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8IE_HIP_TRY(hipMemsetAsync(dst_dev, byte, bytes, ctx->stream));
+  return I8IE_OK;
+}
+
+}  // extern "C"
+
+int i8ie_ws_reserve(i8ie_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->ws_bytes) return I8IE_OK;
+  I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->ws) {
+    I8IE_HIP_TRY(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  size_t want = i8ie_align_up(bytes + bytes / 8, (size_t)1 << 20);
+  hipError_t e = hipMalloc(&ctx->ws, want);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    i8ie_set_error("workspace: out of device memory (%zu bytes)", want);
+    return I8IE_ERR_OOM;
+  }
+  I8IE_HIP_TRY(e);
+  ctx->ws_bytes = want;
+  return I8IE_OK;
+}

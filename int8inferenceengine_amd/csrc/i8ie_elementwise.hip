@@ -1,0 +1,191 @@
+// i8ie_elementwise.hip -- HBM-bound byte/float kernels of the hot path:
+// quantize (a1), dequantize (a6), down_scale (a5), relu u8 (a7), max-pool u8 (a8).
+// All are pure streaming kernels: 16 B per lane per access, grid capped at
+// 256 CUs x 8 blocks and grid-strided (guide: Guideline 11/13).
+// fp32 arithmetic follows SURVEY.md Appendix A exactly (IEEE divide, no FMA
+// contraction: the library is built with -ffp-contract=off).
+#include "i8ie_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 256 * 8;
+
+inline int grid_for(int64_t work_items) {
+  int64_t b = (work_items + kThreads - 1) / kThreads;
+  if (b < 1) b = 1;
+  return (int)(b > kMaxBlocks ? kMaxBlocks : b);
+}
+
+// ---- a1: src/quantize_utils.cc:44-52 ---------------------------------------
+__device__ __forceinline__ uint32_t quant1(float x, float scale, float zpf) {
+  float t = x / scale + zpf;          // divide, then add (no FMA possible)
+  return (uint32_t)((int)t) & 0xFFu;  // truncate, keep the low 8 bits (unclamped cast)
+}
+
+__global__ __launch_bounds__(kThreads) void quantize_kernel(const float* __restrict__ in,
+                                                            uint8_t* __restrict__ out, int64_t n,
+                                                            float scale, float zpf) {
+  const int64_t nvec = n >> 4;  // 16 elements per lane: 4 x float4 in, 1 x uint4 out
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += stride) {
+    const float4* src = reinterpret_cast<const float4*>(in) + v * 4;
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 f = src[j];
+      w[j] = quant1(f.x, scale, zpf) | (quant1(f.y, scale, zpf) << 8) |
+             (quant1(f.z, scale, zpf) << 16) | (quant1(f.w, scale, zpf) << 24);
+    }
+    reinterpret_cast<uint4*>(out)[v] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  // tail (< 16 elements)
+  const int64_t t0 = nvec << 4;
+  if (blockIdx.x == 0 && threadIdx.x < (n - t0))
+    out[t0 + threadIdx.x] = (uint8_t)quant1(in[t0 + threadIdx.x], scale, zpf);
+}
+
+// ---- a6: src/quantize_utils.cc:38-42 ---------------------------------------
+__global__ __launch_bounds__(kThreads) void dequantize_kernel(const uint8_t* __restrict__ in,
+                                                              float* __restrict__ out, int64_t n,
+                                                              float scale, int zp) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
+    out[i] = (float)((int)in[i] - zp) * scale;
+}
+
+// ---- a5: src/quantize_utils.cc:27-36 ---------------------------------------
+__global__ __launch_bounds__(kThreads) void down_scale_kernel(const int32_t* __restrict__ acc,
+                                                              uint8_t* __restrict__ out, int64_t n,
+                                                              float sa, float sb, float sc,
+                                                              float zpf) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    float deq = ((float)acc[i] * sa) * sb;
+    float q = deq / sc + zpf;
+    out[i] = (q >= 255.0f) ? (uint8_t)255 : ((q < 0.0f) ? (uint8_t)0 : (uint8_t)(int)q);
+  }
+}
+
+// ---- a7: src/functional.cc:15-26 -------------------------------------------
+__device__ __forceinline__ uint32_t max_u8x4(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int s = 0; s < 32; s += 8) {
+    uint32_t x = (a >> s) & 0xFFu, y = (b >> s) & 0xFFu;
+    r |= (x > y ? x : y) << s;
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(kThreads) void relu_u8_kernel(const uint8_t* __restrict__ in,
+                                                           uint8_t* __restrict__ out, int64_t n,
+                                                           uint32_t zp4) {
+  const int64_t nvec = n >> 4;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += stride) {
+    uint4 x = reinterpret_cast<const uint4*>(in)[v];
+    x.x = max_u8x4(x.x, zp4);
+    x.y = max_u8x4(x.y, zp4);
+    x.z = max_u8x4(x.z, zp4);
+    x.w = max_u8x4(x.w, zp4);
+    reinterpret_cast<uint4*>(out)[v] = x;
+  }
+  const int64_t t0 = nvec << 4;
+  if (blockIdx.x == 0 && threadIdx.x < (n - t0)) {
+    uint8_t v = in[t0 + threadIdx.x], z = (uint8_t)(zp4 & 0xFF);
+    out[t0 + threadIdx.x] = v > z ? v : z;
+  }
+}
+
+// ---- a8: src/functional.cc:36-64 (NCHW, floor, no padding, running max from 0)
+__global__ __launch_bounds__(kThreads) void maxpool_u8_nchw_kernel(const uint8_t* __restrict__ in,
+                                                                   uint8_t* __restrict__ out,
+                                                                   int64_t total, int h, int w,
+                                                                   int oh, int ow, int k, int s) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += stride) {
+    int x = (int)(e % ow);
+    int64_t t = e / ow;
+    int y = (int)(t % oh);
+    int64_t plane = t / oh;  // img * c + channel
+    const uint8_t* p = in + plane * h * w + (int64_t)(y * s) * w + x * s;
+    uint32_t mx = 0;
+    for (int m = 0; m < k; ++m)
+      for (int l = 0; l < k; ++l) {
+        uint32_t v = p[m * w + l];
+        mx = mx >= v ? mx : v;
+      }
+    out[e] = (uint8_t)mx;
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int i8ie_quantize_f32_u8(i8ie_ctx* ctx, const float* in, uint8_t* out, int64_t n, float scale,
+                         uint8_t zp) {
+  I8IE_REQUIRE(ctx && in && out, "null argument");
+  I8IE_REQUIRE(n >= 0, "negative size");
+  I8IE_REQUIRE(aligned16(in) && aligned16(out), "buffers must be 16-byte aligned");
+  if (n == 0) return I8IE_OK;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  quantize_kernel<<<grid_for((n >> 4) + 1), kThreads, 0, ctx->stream>>>(in, out, n, scale, (float)zp);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+int i8ie_dequantize_u8_f32(i8ie_ctx* ctx, const uint8_t* in, float* out, int64_t n, float scale,
+                           uint8_t zp) {
+  I8IE_REQUIRE(ctx && in && out, "null argument");
+  I8IE_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return I8IE_OK;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  dequantize_kernel<<<grid_for(n), kThreads, 0, ctx->stream>>>(in, out, n, scale, (int)zp);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+int i8ie_down_scale(i8ie_ctx* ctx, const int32_t* acc, uint8_t* out, int64_t n, float sa, float sb,
+                    float sc, uint8_t zp_c) {
+  I8IE_REQUIRE(ctx && acc && out, "null argument");
+  I8IE_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return I8IE_OK;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  down_scale_kernel<<<grid_for(n), kThreads, 0, ctx->stream>>>(acc, out, n, sa, sb, sc, (float)zp_c);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+int i8ie_relu_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int64_t n, uint8_t zp) {
+  I8IE_REQUIRE(ctx && in && out, "null argument");
+  I8IE_REQUIRE(n >= 0, "negative size");
+  I8IE_REQUIRE(aligned16(in) && aligned16(out), "buffers must be 16-byte aligned");
+  if (n == 0) return I8IE_OK;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  uint32_t z = zp;
+  relu_u8_kernel<<<grid_for((n >> 4) + 1), kThreads, 0, ctx->stream>>>(in, out, n,
+                                                                        z | (z << 8) | (z << 16) | (z << 24));
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+int i8ie_maxpool2d_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w,
+                      int k, int s) {
+  I8IE_REQUIRE(ctx && in && out, "null argument");
+  I8IE_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, "non-positive dimension");
+  I8IE_REQUIRE(k > 0 && s > 0, "kernel_size and stride must be positive");
+  I8IE_REQUIRE(k <= h && k <= w, "window larger than the input");
+  int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
+  int64_t total = (int64_t)n * c * oh * ow;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  maxpool_u8_nchw_kernel<<<grid_for(total), kThreads, 0, ctx->stream>>>(in, out, total, h, w, oh, ow,
+                                                                       k, s);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+}  // extern "C"

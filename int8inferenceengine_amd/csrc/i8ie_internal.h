@@ -1,0 +1,73 @@
+// i8ie_internal.h -- shared by the translation units of libi8ie_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+
+#include "i8ie_hip.h"
+
+struct i8ie_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  void* ws = nullptr;  // scratch for one op at a time (stream-ordered reuse)
+  size_t ws_bytes = 0;
+  void* pool = nullptr;  // I8iePool* (i8ie_ctx.hip): stream-ordered caching allocator
+};
+
+void i8ie_set_error(const char* fmt, ...);
+
+#define I8IE_HIP_TRY(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      i8ie_set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return I8IE_ERR_HIP;                                                                  \
+    }                                                                                       \
+  } while (0)
+
+#define I8IE_REQUIRE(cond, msg)                                   \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      i8ie_set_error("%s: %s (%s)", __func__, msg, #cond);        \
+      return I8IE_ERR_ARG;                                        \
+    }                                                             \
+  } while (0)
+
+#define I8IE_TRY(expr)            \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != I8IE_OK) return rc__; \
+  } while (0)
+
+#define I8IE_LAUNCH_CHECK()  I8IE_HIP_TRY(hipGetLastError())
+
+// Make sure ctx->ws holds at least `bytes`; grows by sync + realloc (rare).
+int i8ie_ws_reserve(i8ie_ctx* ctx, size_t bytes);
+
+static inline size_t i8ie_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- GEMM core (i8ie_gemm.hip) ---------------------------------------------
+enum { I8IE_OUT_ROWMAJOR = 0, I8IE_OUT_NCHW = 1 };
+
+struct I8ieGemmArgs {
+  const uint8_t* A;  // u8 [M][lda], rows 16-B aligned, K-contiguous
+  long lda;
+  int M;
+  int Ka;            // readable bytes per A row (multiple of 16)
+  const int8_t* B;   // s8 packed [Npad][Kpad], zero padded, Npad % 128 == 0, Kpad % 64 == 0
+  int Kpad;
+  int N;
+  const int32_t* oc;    // [N] reference offset vector
+  const int32_t* wsum;  // [N] sum_k q_w[j,k] (exact): the u8 -> s8 re-biasing term
+  const int8_t* qb;     // [N] or nullptr: Linear's float bias step
+  float s_in, s_w, s_out;
+  int zp_out;
+  uint8_t* out;
+  int out_mode;  // I8IE_OUT_ROWMAJOR: out[M][N]; I8IE_OUT_NCHW: out[(img*N + j)*P + p], row = img*P + p
+  int P;
+  int32_t* acc;  // nullptr or [M][N]
+};
+int i8ie_gemm_launch(i8ie_ctx* ctx, const I8ieGemmArgs& a);

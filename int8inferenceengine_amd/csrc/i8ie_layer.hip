@@ -1,0 +1,322 @@
+// i8ie_layer.hip -- Linear / Conv2d INT8 forward entry points of the C-ABI:
+// the stateless calls on raw device pointers and the layer handles that keep
+// the converted weights resident (packed for the MFMA kernel) and cache the
+// zero-point offset vector per (s_in, zp_in).
+//   reference: src/fully_connected.cc:22-52, src/conv2d.cc:100-142,
+//              src/layer.cc:6-26,36-54
+#include <cstring>
+#include <new>
+
+#include "i8ie_internal.h"
+
+int i8ie_launch_pad_rows(i8ie_ctx* ctx, const void* src, int rows, int k, void* dst, int rows_pad,
+                         int k_pad, int fill);
+int i8ie_launch_offsets(i8ie_ctx* ctx, bool conv, const int8_t* qw, const int8_t* qb, int n, int K,
+                        float s_in, int zp_in, int32_t* oc, int32_t* wsum);
+int i8ie_launch_im2col(i8ie_ctx* ctx, const uint8_t* in, uint8_t* col, int n, int c, int h, int w, int kh,
+                       int kw, int oh, int ow, int stride, int pad, int K, int Kpad, int zp);
+
+namespace {
+
+constexpr size_t kColBudget = (size_t)192 << 20;  // im2col scratch per chunk: stays in the 256 MiB Infinity Cache
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+struct ConvGeom {
+  int c, h, w, kc, kh, kw, stride, pad, oh, ow, K, Kpad;
+};
+
+// Linear forward given packed weights.
+int linear_run(i8ie_ctx* ctx, const uint8_t* in, int m, int k, const int8_t* Bpack, int Kpad,
+               const int8_t* qb, int n, const int32_t* oc, const int32_t* wsum, float s_in, float s_w,
+               float s_out, uint8_t zp_out, uint8_t* out, int32_t* acc, uint8_t* scratch) {
+  I8ieGemmArgs g{};
+  if (k % 16 != 0 || !aligned16(in)) {
+    // ragged K: copy the activations into a 64-byte-padded image first
+    I8IE_TRY(i8ie_launch_pad_rows(ctx, in, m, k, scratch, m, Kpad, 0));
+    g.A = scratch;
+    g.lda = Kpad;
+    g.Ka = Kpad;
+  } else {
+    g.A = in;
+    g.lda = k;
+    g.Ka = k;
+  }
+  g.M = m;
+  g.B = Bpack;
+  g.Kpad = Kpad;
+  g.N = n;
+  g.oc = oc;
+  g.wsum = wsum;
+  g.qb = qb;
+  g.s_in = s_in;
+  g.s_w = s_w;
+  g.s_out = s_out;
+  g.zp_out = zp_out;
+  g.out = out;
+  g.out_mode = I8IE_OUT_ROWMAJOR;
+  g.P = 1;
+  g.acc = acc;
+  return i8ie_gemm_launch(ctx, g);
+}
+
+// Conv forward given packed weights; the batch is processed in chunks whose
+// im2col image fits kColBudget.
+int conv_run(i8ie_ctx* ctx, const uint8_t* in, int n, const ConvGeom& cg, const int8_t* Bpack,
+             const int32_t* oc, const int32_t* wsum, uint8_t zp_in, float s_in, float s_w, float s_out,
+             uint8_t zp_out, uint8_t* out, int32_t* acc, uint8_t* col, int imgs_per_chunk) {
+  const int P = cg.oh * cg.ow;
+  for (int i0 = 0; i0 < n; i0 += imgs_per_chunk) {
+    const int nb = (n - i0) < imgs_per_chunk ? (n - i0) : imgs_per_chunk;
+    I8IE_TRY(i8ie_launch_im2col(ctx, in + (size_t)i0 * cg.c * cg.h * cg.w, col, nb, cg.c, cg.h, cg.w, cg.kh,
+                                cg.kw, cg.oh, cg.ow, cg.stride, cg.pad, cg.K, cg.Kpad, zp_in));
+    I8ieGemmArgs g{};
+    g.A = col;
+    g.lda = cg.Kpad;
+    g.Ka = cg.Kpad;
+    g.M = nb * P;
+    g.B = Bpack;
+    g.Kpad = cg.Kpad;
+    g.N = cg.kc;
+    g.oc = oc;
+    g.wsum = wsum;
+    g.qb = nullptr;  // conv folds the bias into oc (src/conv2d.cc:123)
+    g.s_in = s_in;
+    g.s_w = s_w;
+    g.s_out = s_out;
+    g.zp_out = zp_out;
+    g.out = out + (size_t)i0 * cg.kc * P;
+    g.out_mode = I8IE_OUT_NCHW;
+    g.P = P;
+    g.acc = acc ? acc + (size_t)i0 * P * cg.kc : nullptr;
+    I8IE_TRY(i8ie_gemm_launch(ctx, g));
+  }
+  return I8IE_OK;
+}
+
+int conv_geom(int c, int h, int w, int kc, int kh, int kw, int stride, int pad, ConvGeom* g) {
+  I8IE_REQUIRE(c > 0 && h > 0 && w > 0 && kc > 0 && kh > 0 && kw > 0, "non-positive dimension");
+  I8IE_REQUIRE(stride > 0, "stride must be positive");  // include/conv2d.h:12-14
+  I8IE_REQUIRE(pad >= 0, "negative padding");
+  I8IE_REQUIRE(h - kh + 2 * pad >= 0 && w - kw + 2 * pad >= 0, "kernel larger than padded input");
+  g->c = c; g->h = h; g->w = w; g->kc = kc; g->kh = kh; g->kw = kw; g->stride = stride; g->pad = pad;
+  g->oh = (h - kh + 2 * pad) / stride + 1;  // src/conv2d.cc:108-109
+  g->ow = (w - kw + 2 * pad) / stride + 1;
+  g->K = c * kh * kw;
+  g->Kpad = round_up(g->K, 64);
+  return I8IE_OK;
+}
+
+inline int chunk_images(const ConvGeom& g, int n) {
+  const size_t per_img = (size_t)g.oh * g.ow * g.Kpad;
+  size_t imgs = kColBudget / per_img;
+  if (imgs < 1) imgs = 1;
+  return imgs > (size_t)n ? n : (int)imgs;
+}
+
+}  // namespace
+
+struct i8ie_layer {
+  i8ie_ctx* ctx = nullptr;
+  bool conv = false;
+  int n = 0, K = 0;  // out features, reduction length
+  int c = 0, kh = 0, kw = 0, stride = 1, pad = 0;
+  int Kpad = 0, Npad = 0;
+  float s_w = 1.0f;
+  float s_out = 1.0f;   // include/layer.h:46
+  uint8_t zp_out = 0;   // include/layer.h:47
+  int8_t* qw = nullptr;     // [n][K] as converted
+  int8_t* qb = nullptr;     // [n]
+  int8_t* Bpack = nullptr;  // [Npad][Kpad], zero padded
+  int32_t* wsum = nullptr;  // [n]
+  int32_t* oc = nullptr;    // [n], valid for (oc_s_in, oc_zp_in)
+  bool oc_valid = false;
+  float oc_s_in = 0.0f;
+  int oc_zp_in = -1;
+};
+
+extern "C" {
+
+int i8ie_conv_offsets(i8ie_ctx* ctx, const int8_t* qw, const int8_t* qb, int kc, int K, float s_in,
+                      uint8_t zp_in, int32_t* oc) {
+  I8IE_REQUIRE(ctx && qw && qb && oc, "null argument");
+  I8IE_REQUIRE(kc > 0 && K > 0, "non-positive dimension");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  return i8ie_launch_offsets(ctx, true, qw, qb, kc, K, s_in, zp_in, oc, nullptr);
+}
+
+int i8ie_linear_offsets(i8ie_ctx* ctx, const int8_t* qw, int n, int k, uint8_t zp_in, int32_t* oc) {
+  I8IE_REQUIRE(ctx && qw && oc, "null argument");
+  I8IE_REQUIRE(n > 0 && k > 0, "non-positive dimension");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  return i8ie_launch_offsets(ctx, false, qw, nullptr, n, k, 0.0f, zp_in, oc, nullptr);
+}
+
+int i8ie_linear_u8s8(i8ie_ctx* ctx, const uint8_t* in, int m, int k, const int8_t* qw, const int8_t* qb,
+                     int n, const int32_t* oc, float s_in, float s_w, float s_out, uint8_t zp_out,
+                     uint8_t* out, int32_t* acc) {
+  I8IE_REQUIRE(ctx && in && qw && qb && oc && out, "null argument");
+  I8IE_REQUIRE(m > 0 && k > 0 && n > 0, "non-positive dimension");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  const int Kpad = round_up(k, 64), Npad = round_up(n, 128);
+  const size_t b_bytes = i8ie_align_up((size_t)Npad * Kpad, 256);
+  const size_t s_bytes = i8ie_align_up((size_t)n * 4, 256);
+  const size_t a_bytes = (size_t)m * Kpad;
+  I8IE_TRY(i8ie_ws_reserve(ctx, b_bytes + s_bytes + a_bytes));
+  uint8_t* ws = (uint8_t*)ctx->ws;
+  int8_t* Bpack = (int8_t*)ws;
+  int32_t* wsum = (int32_t*)(ws + b_bytes);
+  uint8_t* scratch = ws + b_bytes + s_bytes;
+  I8IE_TRY(i8ie_launch_pad_rows(ctx, qw, n, k, Bpack, Npad, Kpad, 0));
+  I8IE_TRY(i8ie_launch_offsets(ctx, false, qw, nullptr, n, k, 0.0f, 0, nullptr, wsum));
+  return linear_run(ctx, in, m, k, Bpack, Kpad, qb, n, oc, wsum, s_in, s_w, s_out, zp_out, out, acc, scratch);
+}
+
+int i8ie_conv2d_u8s8(i8ie_ctx* ctx, const uint8_t* in, int n, int c, int h, int w, const int8_t* qw, int kc,
+                     int kh, int kw, int stride, int pad, uint8_t zp_in, const int32_t* oc, float s_in,
+                     float s_w, float s_out, uint8_t zp_out, uint8_t* out, int32_t* acc) {
+  I8IE_REQUIRE(ctx && in && qw && oc && out, "null argument");
+  I8IE_REQUIRE(n > 0, "non-positive batch");
+  ConvGeom cg;
+  I8IE_TRY(conv_geom(c, h, w, kc, kh, kw, stride, pad, &cg));
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  const int Npad = round_up(kc, 128);
+  const int ipc = chunk_images(cg, n);
+  const size_t b_bytes = i8ie_align_up((size_t)Npad * cg.Kpad, 256);
+  const size_t s_bytes = i8ie_align_up((size_t)kc * 4, 256);
+  const size_t col_bytes = (size_t)ipc * cg.oh * cg.ow * cg.Kpad;
+  I8IE_TRY(i8ie_ws_reserve(ctx, b_bytes + s_bytes + col_bytes));
+  uint8_t* ws = (uint8_t*)ctx->ws;
+  int8_t* Bpack = (int8_t*)ws;
+  int32_t* wsum = (int32_t*)(ws + b_bytes);
+  uint8_t* col = ws + b_bytes + s_bytes;
+  I8IE_TRY(i8ie_launch_pad_rows(ctx, qw, kc, cg.K, Bpack, Npad, cg.Kpad, 0));
+  I8IE_TRY(i8ie_launch_offsets(ctx, true, qw, nullptr, kc, cg.K, 1.0f, 0, nullptr, wsum));
+  return conv_run(ctx, in, n, cg, Bpack, oc, wsum, zp_in, s_in, s_w, s_out, zp_out, out, acc, col, ipc);
+}
+
+// ---- layer handles -------------------------------------------------------------
+static int layer_create(i8ie_ctx* ctx, bool conv, const int8_t* qw_host, const int8_t* qb_host, int n, int K,
+                        int c, int kh, int kw, int stride, int pad, float s_w, i8ie_layer** out) {
+  I8IE_REQUIRE(ctx && qw_host && qb_host && out, "null argument");
+  I8IE_REQUIRE(n > 0 && K > 0, "non-positive dimension");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  i8ie_layer* L = new (std::nothrow) i8ie_layer();
+  if (!L) return I8IE_ERR_OOM;
+  L->ctx = ctx; L->conv = conv; L->n = n; L->K = K; L->c = c; L->kh = kh; L->kw = kw;
+  L->stride = stride; L->pad = pad; L->s_w = s_w;
+  L->Kpad = round_up(K, 64);
+  L->Npad = round_up(n, 128);
+  int rc = I8IE_OK;
+  do {
+    if ((rc = i8ie_malloc(ctx, (size_t)n * K, (void**)&L->qw)) != I8IE_OK) break;
+    if ((rc = i8ie_malloc(ctx, (size_t)n, (void**)&L->qb)) != I8IE_OK) break;
+    if ((rc = i8ie_malloc(ctx, (size_t)L->Npad * L->Kpad, (void**)&L->Bpack)) != I8IE_OK) break;
+    if ((rc = i8ie_malloc(ctx, (size_t)n * 4, (void**)&L->wsum)) != I8IE_OK) break;
+    if ((rc = i8ie_malloc(ctx, (size_t)n * 4, (void**)&L->oc)) != I8IE_OK) break;
+    if ((rc = i8ie_memcpy_h2d(ctx, L->qw, qw_host, (size_t)n * K)) != I8IE_OK) break;
+    if ((rc = i8ie_memcpy_h2d(ctx, L->qb, qb_host, (size_t)n)) != I8IE_OK) break;
+    if ((rc = i8ie_launch_pad_rows(ctx, L->qw, n, K, L->Bpack, L->Npad, L->Kpad, 0)) != I8IE_OK) break;
+    if ((rc = i8ie_launch_offsets(ctx, conv, L->qw, nullptr, n, K, 1.0f, 0, nullptr, L->wsum)) != I8IE_OK) break;
+  } while (0);
+  if (rc != I8IE_OK) {
+    i8ie_layer_destroy(L);
+    return rc;
+  }
+  *out = L;
+  return I8IE_OK;
+}
+
+int i8ie_linear_create(i8ie_ctx* ctx, const int8_t* qw_host, const int8_t* qb_host, int n, int k, float s_w,
+                       i8ie_layer** out) {
+  return layer_create(ctx, false, qw_host, qb_host, n, k, 0, 0, 0, 1, 0, s_w, out);
+}
+
+int i8ie_conv2d_create(i8ie_ctx* ctx, const int8_t* qw_host, const int8_t* qb_host, int kc, int c, int kh,
+                       int kw, int stride, int pad, float s_w, i8ie_layer** out) {
+  I8IE_REQUIRE(c > 0 && kh > 0 && kw > 0, "non-positive dimension");
+  I8IE_REQUIRE(stride > 0, "stride must be positive");
+  I8IE_REQUIRE(pad >= 0, "negative padding");
+  return layer_create(ctx, true, qw_host, qb_host, kc, c * kh * kw, c, kh, kw, stride, pad, s_w, out);
+}
+
+int i8ie_layer_set_output_qparams(i8ie_layer* L, float s_out, uint8_t zp_out) {
+  I8IE_REQUIRE(L != nullptr, "null layer");
+  L->s_out = s_out;
+  L->zp_out = zp_out;
+  return I8IE_OK;
+}
+
+int i8ie_layer_get_output_qparams(const i8ie_layer* L, float* s_out, uint8_t* zp_out) {
+  I8IE_REQUIRE(L && s_out && zp_out, "null argument");
+  *s_out = L->s_out;
+  *zp_out = L->zp_out;
+  return I8IE_OK;
+}
+
+int i8ie_layer_forward(i8ie_layer* L, const uint8_t* in, int m, int h, int w, float s_in, uint8_t zp_in,
+                       uint8_t* out, int32_t* acc) {
+  I8IE_REQUIRE(L && in && out, "null argument");
+  I8IE_REQUIRE(m > 0, "non-positive batch");
+  i8ie_ctx* ctx = L->ctx;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  uint32_t sb_new, sb_old;
+  memcpy(&sb_new, &s_in, 4);
+  memcpy(&sb_old, &L->oc_s_in, 4);
+  if (!L->oc_valid || L->oc_zp_in != (int)zp_in || (L->conv && sb_new != sb_old)) {
+    // the reference recomputes this on every call (src/conv2d.cc:117-124); it only
+    // depends on (s_in, zp_in), which are fixed once the network is converted
+    I8IE_TRY(i8ie_launch_offsets(ctx, L->conv, L->qw, L->qb, L->n, L->K, s_in, zp_in, L->oc, nullptr));
+    L->oc_valid = true;
+    L->oc_s_in = s_in;
+    L->oc_zp_in = zp_in;
+  }
+  if (!L->conv) {
+    const bool need_pad = (L->K % 16 != 0) || !aligned16(in);
+    if (need_pad) I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->Kpad));
+    return linear_run(ctx, in, m, L->K, L->Bpack, L->Kpad, L->qb, L->n, L->oc, L->wsum, s_in, L->s_w,
+                      L->s_out, L->zp_out, out, acc, (uint8_t*)ctx->ws);
+  }
+  ConvGeom cg;
+  I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
+  const int ipc = chunk_images(cg, m);
+  I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)ipc * cg.oh * cg.ow * cg.Kpad));
+  return conv_run(ctx, in, m, cg, L->Bpack, L->oc, L->wsum, zp_in, s_in, L->s_w, L->s_out, L->zp_out, out,
+                  acc, (uint8_t*)ctx->ws, ipc);
+}
+
+int i8ie_layer_destroy(i8ie_layer* L) {
+  if (!L) return I8IE_OK;
+  i8ie_ctx* ctx = L->ctx;
+  i8ie_free(ctx, L->qw);
+  i8ie_free(ctx, L->qb);
+  i8ie_free(ctx, L->Bpack);
+  i8ie_free(ctx, L->wsum);
+  i8ie_free(ctx, L->oc);
+  delete L;
+  return I8IE_OK;
+}
+
+// quantize_weight, src/layer.cc:6-26 (host side, one-shot at convert())
+int i8ie_quantize_weight(const float* w, int64_t nw, const float* b, int64_t nb, int8_t* qw, int8_t* qb,
+                         float* scale_out) {
+  I8IE_REQUIRE(w && b && qw && qb && scale_out, "null argument");
+  I8IE_REQUIRE(nw > 0 && nb > 0, "empty tensor");
+  float mx = -3.402823466e+38f, mn = 3.402823466e+38f;
+  for (int64_t i = 0; i < nw; ++i) {
+    mn = w[i] < mn ? w[i] : mn;
+    mx = w[i] > mx ? w[i] : mx;
+  }
+  for (int64_t i = 0; i < nb; ++i) {
+    mn = b[i] < mn ? b[i] : mn;
+    mx = b[i] > mx ? b[i] : mx;
+  }
+  const float s = (mx - mn) / 127;
+  for (int64_t i = 0; i < nw; ++i) qw[i] = (int8_t)(int32_t)(w[i] / s);
+  for (int64_t i = 0; i < nb; ++i) qb[i] = (int8_t)(int32_t)(b[i] / s);
+  *scale_out = s;
+  return I8IE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,635 @@
+// pybind_module.cc -- the rebuilt extension module `_CXX_i8ie`.
+//
+// Same Python-visible surface as the reference's module (src/pybind11.cc:37-55,
+// declare_linear src/fully_connected.cc:54-72, declare_conv2d
+// src/conv2d.cc:144-165, declare_tensor_funcs src/functional.cc:66-82), but
+// every tensor lives in MI355X HBM and every op is a HIP kernel reached through
+// the C-ABI of libi8ie_hip.so (include/i8ie_hip.h).  This file contains no HIP
+// code and no arithmetic of the hot path: only ownership, shapes, the
+// prepare/convert state machine (src/layer.cc:28-54) and the calibrator
+// (src/calibrator.cc).  There is no CPU fallback: if the library or a GPU is
+// missing, calls raise RuntimeError.
+//
+// Additive API (not in the reference; needed for parity tests and benchmarks):
+//   layer.set_output_qparams(scale, zp) / output_qparams() / q_weight() /
+//   q_bias() / weight_scale() / forward_debug(u8 tensor) -> (out, int32 acc);
+//   tensor.prefetch();  module: set_device, device, synchronize, memory_stats,
+//   set_calibration_seed, abi_version.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "i8ie_hip.h"
+#include "pybind11/numpy.h"
+#include "pybind11/pybind11.h"
+#include "pybind11/stl.h"
+
+namespace py = pybind11;
+using u8_t = unsigned char;
+using s8_t = signed char;
+
+namespace {
+
+// ---------------------------------------------------------------- runtime ----
+struct Runtime {
+  i8ie_ctx* ctx = nullptr;
+  int device = -1;
+  long calib_seed = -1;  // < 0: std::random_device, as the reference (src/calibrator.cc:9-10)
+};
+Runtime& rt() {
+  static Runtime* r = new Runtime();  // intentionally leaked: outlives every tensor at exit
+  return *r;
+}
+void check(int rc) {
+  if (rc != I8IE_OK) throw std::runtime_error(std::string("i8ie: ") + i8ie_last_error());
+}
+int default_device() {
+  if (const char* e = std::getenv("I8IE_DEVICE")) return std::atoi(e);
+  if (const char* e = std::getenv("LOCAL_RANK")) return std::atoi(e);  // one process per GPU
+  return 0;
+}
+i8ie_ctx* ctx() {
+  Runtime& r = rt();
+  if (!r.ctx) {
+    if (r.device < 0) r.device = default_device();
+    check(i8ie_ctx_create(r.device, &r.ctx));
+  }
+  return r.ctx;
+}
+
+// ---------------------------------------------------------------- storage ----
+// One buffer shared by a tensor and its reshape views (the role of the
+// py::capsule in include/tensor.h:28,94-104).  A host mirror is kept for
+// tensors that came from numpy so that small host-side round trips
+// (argmax / == / sum in i8ie/__init__.py) do not touch the device.
+struct Storage {
+  size_t bytes = 0;
+  void* dev = nullptr;
+  std::vector<unsigned char> host;
+  bool host_valid = false;
+  ~Storage() {
+    if (dev && rt().ctx) i8ie_free(rt().ctx, dev);
+  }
+  void* device_ptr() {
+    if (!dev) {
+      check(i8ie_malloc(ctx(), bytes, &dev));
+      if (host_valid) {
+        py::gil_scoped_release nogil;
+        check(i8ie_memcpy_h2d(ctx(), dev, host.data(), bytes));
+      }
+      if (bytes > (1u << 20)) {  // keep the mirror only for small tensors
+        std::vector<unsigned char>().swap(host);
+        host_valid = false;
+      }
+    }
+    return dev;
+  }
+  void read_back(void* dst) {
+    if (host_valid) {
+      std::memcpy(dst, host.data(), bytes);
+      return;
+    }
+    py::gil_scoped_release nogil;
+    check(i8ie_memcpy_d2h(ctx(), dst, dev, bytes));
+  }
+};
+
+std::shared_ptr<Storage> device_storage(size_t bytes) {
+  auto s = std::make_shared<Storage>();
+  s->bytes = bytes;
+  check(i8ie_malloc(ctx(), bytes, &s->dev));
+  return s;
+}
+
+// ----------------------------------------------------------------- tensor ----
+template <typename T>
+struct Tensor {
+  std::shared_ptr<Storage> st;
+  std::vector<ssize_t> shape;
+  ssize_t size = 0;
+  float scale = 1;      // include/tensor.h:153
+  u8_t zero_point = 0;  // include/tensor.h:154
+
+  Tensor() = default;
+  explicit Tensor(std::vector<ssize_t> shp) : shape(std::move(shp)) {
+    size = 1;
+    for (ssize_t d : shape) size *= d;
+    st = device_storage((size_t)size * sizeof(T));
+  }
+  T* dptr() const {
+    if (!st) throw std::runtime_error("i8ie: empty tensor");
+    return static_cast<T*>(st->device_ptr());
+  }
+  py::array_t<T> numpy() const {
+    py::array_t<T> out(shape);
+    if (st && size > 0) st->read_back(out.mutable_data());
+    return out;
+  }
+  // include/tensor.h:106-133: at most one -1, no zeros, sizes must match
+  Tensor<T> reshape(std::vector<ssize_t> shp) const {
+    ssize_t midx = -1, sz = 1;
+    for (size_t i = 0; i < shp.size(); ++i) {
+      if (shp[i] < 0) {
+        if (midx != -1) throw std::runtime_error("i8ie: reshape: more than one negative dimension");
+        midx = (ssize_t)i;
+      } else if (shp[i] == 0) {
+        throw std::runtime_error("i8ie: reshape: zero dimension");
+      } else {
+        sz *= shp[i];
+      }
+    }
+    if (midx >= 0) {
+      if (size % sz != 0) throw std::runtime_error("i8ie: reshape: size is not divisible");
+      shp[midx] = size / sz;
+      sz *= shp[midx];
+    }
+    if (sz != size) throw std::runtime_error("i8ie: reshape: element count differs");
+    Tensor<T> v;
+    v.st = st;
+    v.shape = std::move(shp);
+    v.size = size;
+    v.scale = scale;
+    v.zero_point = zero_point;
+    return v;
+  }
+};
+
+Tensor<float> tensor_from_numpy(py::array_t<float, py::array::c_style | py::array::forcecast> a) {
+  Tensor<float> t;  // include/tensor.h:40-47: copies the ndarray
+  t.shape.assign(a.shape(), a.shape() + a.ndim());
+  t.size = a.size();
+  t.st = std::make_shared<Storage>();
+  t.st->bytes = (size_t)t.size * sizeof(float);
+  t.st->host.resize(t.st->bytes);
+  if (t.st->bytes) std::memcpy(t.st->host.data(), a.data(), t.st->bytes);
+  t.st->host_valid = true;
+  return t;
+}
+
+template <typename T>
+void bind_tensor(py::module_& m, const char* name) {
+  py::class_<Tensor<T>>(m, name)
+      .def(py::init<>())
+      .def("numpy", &Tensor<T>::numpy)
+      .def("zero_point", [](const Tensor<T>& t) { return t.zero_point; })
+      .def("scale", [](const Tensor<T>& t) { return t.scale; })
+      .def("sum",
+           [](const Tensor<T>& t) {  // src/pybind11.cc:18-25: sequential fp32 sum
+             py::array_t<T> a = t.numpy();
+             const T* p = a.data();
+             float s = 0;
+             for (ssize_t i = 0; i < t.size; ++i) s += p[i];
+             return s;
+           })
+      .def("ref_count", [](const Tensor<T>& t) { return t.st ? (long)t.st.use_count() : 0L; })
+      .def("reshape", [](const Tensor<T>& t, std::vector<ssize_t> shape) { return t.reshape(std::move(shape)); })
+      .def("prefetch", [](Tensor<T>& t) { (void)t.dptr(); })
+      .def("nbytes", [](const Tensor<T>& t) { return (size_t)t.size * sizeof(T); });
+}
+
+// ------------------------------------------------------------ elementwise ----
+Tensor<u8_t> quantize(Tensor<float>& in, float scale, u8_t zp) {  // src/quantize_utils.cc:44-52
+  Tensor<u8_t> out(in.shape);
+  out.scale = scale;
+  out.zero_point = zp;
+  check(i8ie_quantize_f32_u8(ctx(), in.dptr(), out.dptr(), in.size, scale, zp));
+  return out;
+}
+Tensor<float> dequantize(Tensor<u8_t>& in) {  // src/quantize_utils.cc:54-58
+  Tensor<float> out(in.shape);
+  check(i8ie_dequantize_u8_f32(ctx(), in.dptr(), out.dptr(), in.size, in.scale, in.zero_point));
+  return out;
+}
+Tensor<u8_t> relu_u8(Tensor<u8_t>& in) {  // src/functional.cc:15-26
+  Tensor<u8_t> out(in.shape);
+  out.scale = in.scale;
+  out.zero_point = in.zero_point;
+  check(i8ie_relu_u8(ctx(), in.dptr(), out.dptr(), in.size, in.zero_point));
+  return out;
+}
+Tensor<float> relu_f32(Tensor<float>& in) {  // src/functional.cc:5-13
+  Tensor<float> out(in.shape);
+  check(i8ie_relu_f32(ctx(), in.dptr(), out.dptr(), in.size));
+  return out;
+}
+template <typename T>
+std::vector<ssize_t> pool_shape(const Tensor<T>& in, ssize_t k, ssize_t s) {
+  if (in.shape.size() != 4) throw std::runtime_error("i8ie: max_pool2d expects an NCHW tensor");
+  if (k <= 0 || s <= 0) throw std::runtime_error("i8ie: max_pool2d: kernel_size and stride must be positive");
+  if (k > in.shape[2] || k > in.shape[3]) throw std::runtime_error("i8ie: max_pool2d: window larger than input");
+  return {in.shape[0], in.shape[1], (in.shape[2] - k) / s + 1, (in.shape[3] - k) / s + 1};
+}
+Tensor<u8_t> max_pool2d_u8(Tensor<u8_t>& in, ssize_t k, ssize_t s) {  // src/functional.cc:36-64
+  Tensor<u8_t> out(pool_shape(in, k, s));
+  out.scale = in.scale;
+  out.zero_point = in.zero_point;
+  check(i8ie_maxpool2d_u8(ctx(), in.dptr(), out.dptr(), (int)in.shape[0], (int)in.shape[1], (int)in.shape[2],
+                          (int)in.shape[3], (int)k, (int)s));
+  return out;
+}
+Tensor<float> max_pool2d_f32(Tensor<float>& in, ssize_t k, ssize_t s) {
+  Tensor<float> out(pool_shape(in, k, s));
+  check(i8ie_maxpool2d_f32(ctx(), in.dptr(), out.dptr(), (int)in.shape[0], (int)in.shape[1], (int)in.shape[2],
+                           (int)in.shape[3], (int)k, (int)s));
+  return out;
+}
+
+// -------------------------------------------------------------- calibrator ----
+// src/calibrator.cc:6-37, include/calibrator.h:4-14
+constexpr ssize_t kNumSamples = 1000;
+struct Calibrator {
+  std::array<float, kNumSamples> samples{};  // value-initialised (make_unique<Calibrator>(), src/layer.cc:33)
+  ssize_t cnt = 0;
+  void sample(const float* data, ssize_t n) {
+    std::mt19937 rng;
+    if (rt().calib_seed >= 0) {
+      rng.seed((unsigned)rt().calib_seed);
+    } else {
+      std::random_device rd;
+      rng.seed(rd());
+    }
+    std::uniform_int_distribution<ssize_t> dist(0, kNumSamples * 2);  // about half get sampled
+    for (ssize_t i = 0; i < n; ++i) {
+      if (cnt < kNumSamples) {
+        samples[cnt++] = data[i];
+      } else {
+        ssize_t idx = dist(rng);
+        if (idx < kNumSamples) samples[idx] = data[i];
+      }
+    }
+  }
+  std::tuple<float, u8_t> get_range(float quantile) {
+    std::sort(samples.begin(), samples.end());
+    float out_min = samples[(size_t)((1.0 - quantile) * cnt)];
+    float out_max = samples[(size_t)(quantile * (cnt - 1))];
+    out_min = std::fmin(out_min, 0.);
+    out_max = std::fmax(out_max, 0.);
+    u8_t zp = (u8_t)(255 * (0 - out_min) / (out_max - out_min + 1e-09));
+    float scale = (zp == 0) ? (out_max - out_min) / 255 : (0 - out_min) / zp;
+    if (scale == 0) scale = 1;
+    return std::make_tuple(scale, zp);
+  }
+};
+
+// ------------------------------------------------------------------ layers ----
+class BaseLayer {
+ public:
+  BaseLayer(std::vector<ssize_t> wshape, ssize_t out_channel) : wshape_(std::move(wshape)) {
+    ssize_t n = 1;
+    for (ssize_t d : wshape_) n *= d;
+    w_.assign((size_t)n, 0.0f);
+    b_.assign((size_t)out_channel, 0.0f);
+    has_fp32_ = true;
+  }
+  BaseLayer(py::array_t<float, py::array::c_style | py::array::forcecast> w,
+            py::array_t<float, py::array::c_style | py::array::forcecast> b) {
+    has_fp32_ = true;
+    load_weight(w);
+    load_bias(b);
+  }
+  virtual ~BaseLayer() {
+    release_fp32_dev();
+    if (q_) i8ie_layer_destroy(q_);
+  }
+  BaseLayer(const BaseLayer&) = delete;
+  BaseLayer& operator=(const BaseLayer&) = delete;
+
+  void load_weight(py::array_t<float, py::array::c_style | py::array::forcecast> w) {  // include/layer.h:15-20
+    if (!has_fp32_) throw std::runtime_error("i8ie: load_weight: layer is already converted");
+    wshape_.assign(w.shape(), w.shape() + w.ndim());
+    w_.assign(w.data(), w.data() + w.size());
+    release_fp32_dev();
+  }
+  void load_bias(py::array_t<float, py::array::c_style | py::array::forcecast> b) {  // include/layer.h:21-26
+    if (!has_fp32_) throw std::runtime_error("i8ie: load_bias: layer is already converted");
+    b_.assign(b.data(), b.data() + b.size());
+    release_fp32_dev();
+  }
+  void prepare() {  // src/layer.cc:28-35
+    if (is_quantized_) {
+      std::cerr << "already quantized" << std::endl;
+      return;
+    }
+    cal_ = std::make_unique<Calibrator>();
+    is_preparing_ = true;
+  }
+  void convert() {  // src/layer.cc:36-54
+    if (is_quantized_) {
+      std::cerr << "already quantized" << std::endl;
+      return;
+    }
+    if (!is_preparing_) {
+      if (!qparams_overridden_) std::cerr << "No prepared, use default config" << std::endl;
+    } else {
+      float s;
+      u8_t z;
+      std::tie(s, z) = cal_->get_range(1);
+      if (!qparams_overridden_) {
+        scale_ = s;
+        zero_point_ = z;
+      }
+      cal_.reset();
+    }
+    check_shapes();
+    const ssize_t n = (ssize_t)b_.size();
+    qw_.resize(w_.size());
+    qb_.resize(b_.size());
+    check(i8ie_quantize_weight(w_.data(), (int64_t)w_.size(), b_.data(), (int64_t)b_.size(),
+                               reinterpret_cast<int8_t*>(qw_.data()), reinterpret_cast<int8_t*>(qb_.data()),
+                               &w_scale_));
+    make_handle(n);
+    check(i8ie_layer_set_output_qparams(q_, scale_, zero_point_));
+    is_preparing_ = false;
+    is_quantized_ = true;
+    std::vector<float>().swap(w_);  // src/layer.cc:52-53: FP32 weights are released
+    std::vector<float>().swap(b_);
+    has_fp32_ = false;
+    release_fp32_dev();
+  }
+  void set_output_qparams(float s, int zp) {  // additive: inject what calibration would produce
+    if (zp < 0 || zp > 255) throw std::runtime_error("i8ie: zero point must be in [0, 255]");
+    scale_ = s;
+    zero_point_ = (u8_t)zp;
+    qparams_overridden_ = true;
+    if (q_) check(i8ie_layer_set_output_qparams(q_, scale_, zero_point_));
+  }
+  std::tuple<float, int> output_qparams() const { return std::make_tuple(scale_, (int)zero_point_); }
+  py::array_t<s8_t> q_weight() const {
+    need_quantized();
+    py::array_t<s8_t> a(wshape_);
+    std::memcpy(a.mutable_data(), qw_.data(), qw_.size());
+    return a;
+  }
+  py::array_t<s8_t> q_bias() const {
+    need_quantized();
+    py::array_t<s8_t> a((ssize_t)qb_.size());
+    std::memcpy(a.mutable_data(), qb_.data(), qb_.size());
+    return a;
+  }
+  float weight_scale() const {
+    need_quantized();
+    return w_scale_;
+  }
+  bool is_quantized() const { return is_quantized_; }
+
+ protected:
+  virtual void check_shapes() const = 0;
+  virtual void make_handle(ssize_t n) = 0;
+  void need_quantized() const {
+    if (!is_quantized_) throw std::runtime_error("i8ie: layer is not converted (call convert() first)");
+  }
+  void need_fp32() const {
+    if (!has_fp32_)
+      throw std::runtime_error("i8ie: FP32 input given to a converted layer (its FP32 weights were released)");
+  }
+  void upload_fp32() {
+    if (w_dev_) return;
+    check(i8ie_malloc(ctx(), w_.size() * 4, (void**)&w_dev_));
+    check(i8ie_malloc(ctx(), b_.size() * 4, (void**)&b_dev_));
+    check(i8ie_memcpy_h2d(ctx(), w_dev_, w_.data(), w_.size() * 4));
+    check(i8ie_memcpy_h2d(ctx(), b_dev_, b_.data(), b_.size() * 4));
+  }
+  void release_fp32_dev() {
+    if (rt().ctx) {
+      if (w_dev_) i8ie_free(rt().ctx, w_dev_);
+      if (b_dev_) i8ie_free(rt().ctx, b_dev_);
+    }
+    w_dev_ = b_dev_ = nullptr;
+  }
+  void maybe_sample(const Tensor<float>& out) {  // src/conv2d.cc:94-96, src/fully_connected.cc:17-19
+    if (!is_preparing_) return;
+    py::array_t<float> a = out.numpy();
+    cal_->sample(a.data(), out.size);
+  }
+
+  std::vector<ssize_t> wshape_;
+  std::vector<float> w_, b_;
+  bool has_fp32_ = false;
+  float* w_dev_ = nullptr;
+  float* b_dev_ = nullptr;
+  std::vector<s8_t> qw_, qb_;
+  float w_scale_ = 1;
+  std::unique_ptr<Calibrator> cal_;
+  bool is_preparing_ = false;
+  bool is_quantized_ = false;
+  bool qparams_overridden_ = false;
+  float scale_ = 1;       // include/layer.h:46
+  u8_t zero_point_ = 0;   // include/layer.h:47
+  i8ie_layer* q_ = nullptr;
+};
+
+class Linear : public BaseLayer {
+ public:
+  Linear(ssize_t in_channel, ssize_t out_channel) : BaseLayer({out_channel, in_channel}, out_channel) {}
+  using BaseLayer::BaseLayer;
+
+  Tensor<float> forward_f32(Tensor<float>& in) {  // src/fully_connected.cc:5-21
+    need_fp32();
+    check_shapes();
+    const ssize_t n = wshape_[0], k = wshape_[1];
+    if (in.shape.empty() || in.size % k != 0 || in.shape.back() != k)
+      throw std::runtime_error("i8ie: Linear: input's last dimension must equal in_features");
+    const ssize_t m = in.size / k;
+    upload_fp32();
+    Tensor<float> out({m, n});
+    check(i8ie_linear_f32(ctx(), in.dptr(), (int)m, (int)k, w_dev_, b_dev_, (int)n, out.dptr()));
+    maybe_sample(out);
+    return out;
+  }
+  std::tuple<Tensor<u8_t>, py::object> forward_u8(Tensor<u8_t>& in, bool want_acc) {  // src/fully_connected.cc:22-52
+    need_quantized();
+    const ssize_t n = wshape_[0], k = wshape_[1];
+    if (in.shape.empty() || in.shape.back() != k)
+      throw std::runtime_error("i8ie: Linear: input's last dimension must equal in_features");
+    const ssize_t m = in.size / k;
+    Tensor<u8_t> out({m, n});
+    out.scale = scale_;
+    out.zero_point = zero_point_;
+    py::object acc_np = py::none();
+    if (want_acc) {
+      Tensor<int32_t> acc({m, n});
+      check(i8ie_layer_forward(q_, in.dptr(), (int)m, 0, 0, in.scale, in.zero_point, out.dptr(), acc.dptr()));
+      acc_np = acc.numpy();
+    } else {
+      check(i8ie_layer_forward(q_, in.dptr(), (int)m, 0, 0, in.scale, in.zero_point, out.dptr(), nullptr));
+    }
+    return std::make_tuple(std::move(out), acc_np);
+  }
+
+ protected:
+  void check_shapes() const override {
+    if (wshape_.size() != 2) throw std::runtime_error("i8ie: Linear weight must be [out_features, in_features]");
+    if (has_fp32_ && (ssize_t)b_.size() != wshape_[0]) throw std::runtime_error("i8ie: Linear bias size mismatch");
+  }
+  void make_handle(ssize_t n) override {
+    check(i8ie_linear_create(ctx(), reinterpret_cast<const int8_t*>(qw_.data()),
+                             reinterpret_cast<const int8_t*>(qb_.data()), (int)n, (int)wshape_[1], w_scale_, &q_));
+  }
+};
+
+class Conv2d : public BaseLayer {
+ public:
+  Conv2d(ssize_t in_channel, ssize_t out_channel, ssize_t kernel_size, ssize_t stride, ssize_t padding)
+      : BaseLayer({out_channel, in_channel, kernel_size, kernel_size}, out_channel),
+        stride_(stride), padding_(padding) {
+    if (stride == 0) throw std::runtime_error("i8ie: Conv2d: stride must not be 0");  // include/conv2d.h:12-14
+    if (stride < 0 || padding < 0) throw std::runtime_error("i8ie: Conv2d: negative stride/padding");
+  }
+  // include/conv2d.h:16-17 leaves stride_/padding_ uninitialised for these two
+  // constructors; they are 1 / 0 here.
+  Conv2d(py::array_t<float, py::array::c_style | py::array::forcecast> w,
+         py::array_t<float, py::array::c_style | py::array::forcecast> b)
+      : BaseLayer(w, b) {}
+
+  std::vector<ssize_t> out_shape(const std::vector<ssize_t>& s) const {
+    if (s.size() != 4) throw std::runtime_error("i8ie: Conv2d expects an NCHW tensor");
+    if (s[1] != wshape_[1]) throw std::runtime_error("i8ie: Conv2d: input channels do not match the weight");
+    const ssize_t kh = wshape_[2], kw = wshape_[3];
+    if (s[2] - kh + 2 * padding_ < 0 || s[3] - kw + 2 * padding_ < 0)
+      throw std::runtime_error("i8ie: Conv2d: kernel larger than the padded input");
+    return {s[0], wshape_[0], (s[2] - kh + 2 * padding_) / stride_ + 1, (s[3] - kw + 2 * padding_) / stride_ + 1};
+  }
+  Tensor<float> forward_f32(Tensor<float>& in) {  // src/conv2d.cc:63-98
+    need_fp32();
+    check_shapes();
+    Tensor<float> out(out_shape(in.shape));
+    upload_fp32();
+    check(i8ie_conv2d_f32(ctx(), in.dptr(), (int)in.shape[0], (int)in.shape[1], (int)in.shape[2], (int)in.shape[3],
+                          w_dev_, b_dev_, (int)wshape_[0], (int)wshape_[2], (int)wshape_[3], (int)stride_,
+                          (int)padding_, out.dptr()));
+    maybe_sample(out);
+    return out;
+  }
+  std::tuple<Tensor<u8_t>, py::object> forward_u8(Tensor<u8_t>& in, bool want_acc) {  // src/conv2d.cc:100-142
+    need_quantized();
+    Tensor<u8_t> out(out_shape(in.shape));
+    out.scale = scale_;
+    out.zero_point = zero_point_;
+    py::object acc_np = py::none();
+    const int n = (int)in.shape[0], h = (int)in.shape[2], w = (int)in.shape[3];
+    if (want_acc) {
+      Tensor<int32_t> acc({out.shape[0], out.shape[2] * out.shape[3], out.shape[1]});
+      check(i8ie_layer_forward(q_, in.dptr(), n, h, w, in.scale, in.zero_point, out.dptr(), acc.dptr()));
+      acc_np = acc.numpy();
+    } else {
+      check(i8ie_layer_forward(q_, in.dptr(), n, h, w, in.scale, in.zero_point, out.dptr(), nullptr));
+    }
+    return std::make_tuple(std::move(out), acc_np);
+  }
+
+ protected:
+  void check_shapes() const override {
+    if (wshape_.size() != 4) throw std::runtime_error("i8ie: Conv2d weight must be [out, in, kh, kw]");
+    if (has_fp32_ && (ssize_t)b_.size() != wshape_[0]) throw std::runtime_error("i8ie: Conv2d bias size mismatch");
+  }
+  void make_handle(ssize_t n) override {
+    check(i8ie_conv2d_create(ctx(), reinterpret_cast<const int8_t*>(qw_.data()),
+                             reinterpret_cast<const int8_t*>(qb_.data()), (int)n, (int)wshape_[1], (int)wshape_[2],
+                             (int)wshape_[3], (int)stride_, (int)padding_, w_scale_, &q_));
+  }
+
+ private:
+  ssize_t stride_ = 1;
+  ssize_t padding_ = 0;
+};
+
+template <typename L>
+void bind_layer_common(py::class_<L>& c) {
+  c.def("load_weight", &L::load_weight)
+      .def("load_bias", &L::load_bias)
+      .def("prepare", &L::prepare)
+      .def("convert", &L::convert)
+      .def("__call__", [](L& l, Tensor<float>& x) { return l.forward_f32(x); })
+      .def("__call__", [](L& l, Tensor<u8_t>& x) { return std::get<0>(l.forward_u8(x, false)); })
+      .def("forward_debug", [](L& l, Tensor<u8_t>& x) { return l.forward_u8(x, true); })
+      .def("set_output_qparams", &L::set_output_qparams, py::arg("scale"), py::arg("zero_point"))
+      .def("output_qparams", &L::output_qparams)
+      .def("q_weight", &L::q_weight)
+      .def("q_bias", &L::q_bias)
+      .def("weight_scale", &L::weight_scale)
+      .def("is_quantized", &L::is_quantized);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_CXX_i8ie, m) {
+  m.doc() = "i8ie extension module: MI355X (gfx950) HIP backend behind include/i8ie_hip.h";
+
+  // the reference registers Tensor<T> under typeid(...).name() (src/pybind11.cc:12)
+  bind_tensor<float>(m, "6TensorIfE");
+  bind_tensor<u8_t>(m, "6TensorIhE");
+  bind_tensor<s8_t>(m, "6TensorIcE");
+  py::class_<Tensor<int32_t>>(m, "6TensorIiE").def("numpy", &Tensor<int32_t>::numpy);
+
+  m.def("tensor", &tensor_from_numpy);  // src/pybind11.cc:38-40
+  m.def("quantize", &quantize);         // src/pybind11.cc:41-45
+  m.def("dequantize", &dequantize);     // src/pybind11.cc:46-48
+  m.def("relu", &relu_f32);             // src/functional.cc:73-75
+  m.def("relu", &relu_u8);
+  m.def("max_pool2d", &max_pool2d_f32);  // src/functional.cc:68-72
+  m.def("max_pool2d", &max_pool2d_u8);
+
+  {
+    py::class_<Linear> c(m, "Linear");  // src/fully_connected.cc:54-72
+    c.def(py::init<py::array_t<float, py::array::c_style | py::array::forcecast>,
+                   py::array_t<float, py::array::c_style | py::array::forcecast>>())
+        .def(py::init([](Tensor<float>& w, Tensor<float>& b) { return new Linear(w.numpy(), b.numpy()); }))
+        .def(py::init<ssize_t, ssize_t>());
+    bind_layer_common(c);
+  }
+  {
+    py::class_<Conv2d> c(m, "Conv2d");  // src/conv2d.cc:144-165
+    c.def(py::init<py::array_t<float, py::array::c_style | py::array::forcecast>,
+                   py::array_t<float, py::array::c_style | py::array::forcecast>>())
+        .def(py::init([](Tensor<float>& w, Tensor<float>& b) { return new Conv2d(w.numpy(), b.numpy()); }))
+        .def(py::init<ssize_t, ssize_t, ssize_t, ssize_t, ssize_t>(), py::arg("in_channels"),
+             py::arg("out_channels"), py::arg("kernel_size"), py::arg("stride") = 1, py::arg("padding") = 0);
+    bind_layer_common(c);
+  }
+
+  // ---- additive runtime controls -------------------------------------------------
+  m.def("abi_version", []() { return i8ie_version(); });
+  m.def("device_count", []() {
+    int n = 0;
+    check(i8ie_device_count(&n));
+    return n;
+  });
+  m.def("set_device", [](int d) {
+    if (rt().ctx && rt().device != d) throw std::runtime_error("i8ie: set_device after the context was created");
+    rt().device = d;
+  });
+  m.def("device", []() {
+    (void)ctx();
+    return rt().device;
+  });
+  m.def("synchronize", []() {
+    py::gil_scoped_release nogil;
+    check(i8ie_sync(ctx()));
+  });
+  m.def("stream", []() { return (uintptr_t)i8ie_ctx_stream(ctx()); });
+  m.def("memory_stats", []() {
+    size_t live = 0, cached = 0, allocs = 0;
+    check(i8ie_memory_stats(ctx(), &live, &cached, &allocs));
+    return py::make_tuple(live, cached, allocs);
+  });
+  m.def("trim", []() { check(i8ie_trim(ctx())); });
+  m.def("set_calibration_seed", [](long seed) { rt().calib_seed = seed; });
+  // raw device copy into / out of foreign HIP memory (e.g. a torch tensor's data_ptr) for the
+  // multi-GPU logits gather; both sides must be used on this module's stream or synchronised.
+  m.def("copy_to_ptr", [](Tensor<float>& t, uintptr_t dst) {
+    check(i8ie_memcpy_d2d(ctx(), (void*)dst, t.dptr(), (size_t)t.size * 4));
+  });
+  m.def("copy_to_ptr", [](Tensor<u8_t>& t, uintptr_t dst) {
+    check(i8ie_memcpy_d2d(ctx(), (void*)dst, t.dptr(), (size_t)t.size));
+  });
+}

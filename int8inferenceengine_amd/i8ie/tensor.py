@@ -1,0 +1,58 @@
+"""Tensor wrapper (reference i8ie/tensor.py:4-37)."""
+import _CXX_i8ie as _C
+
+
+class Tensor:
+    """Thin handle around an extension tensor (`.data`): float32, uint8 or int8.
+
+    Quantised tensors carry a per-tensor `scale` and `zero_point`
+    (reference include/tensor.h:152-154).
+    """
+
+    __slots__ = ("data",)
+
+    def __init__(self, data):
+        self.data = data
+
+    def numpy(self):
+        """Host copy of the contents (device -> host)."""
+        return self.data.numpy()
+
+    @property
+    def shape(self):
+        return self.numpy().shape
+
+    @property
+    def scale(self):
+        return self.data.scale()
+
+    @property
+    def zero_point(self):
+        return self.data.zero_point()
+
+    @property
+    def dtype(self):
+        # the reference's property body is `pass` (i8ie/tensor.py:35-37): always None
+        return None
+
+    def reshape(self, *dims):
+        """A view sharing the same buffer; one dimension may be -1 (reference :14-15)."""
+        return Tensor(self.data.reshape(list(dims)))
+
+    def sum(self):
+        return self.numpy().sum()
+
+    def prefetch(self):
+        """Additive: upload a host-created tensor to the GPU now instead of at first use."""
+        self.data.prefetch()
+        return self
+
+    def __eq__(self, other):
+        # element-wise equality as a float tensor (reference :11-12); NOT wrapped in Tensor there either
+        return _C.tensor(self.numpy() == other.numpy())
+
+    __hash__ = None
+
+    def __repr__(self):
+        # prints de-quantised values (reference :8-9)
+        return repr((self.numpy() - self.zero_point) * self.scale)

@@ -1,0 +1,223 @@
+"""ctypes binding of libi8ie_hip.so used by the tests (and a model of the stub an
+FFI user would write).  numpy in, numpy out; every call goes
+through the C-ABI declared in include/i8ie_hip.h."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "int8inferenceengine_amd", "libi8ie_hip.so")
+HEADER = os.path.join(ROOT, "include", "i8ie_hip.h")
+
+_lib = None
+
+
+def declared_symbols():
+    """Every function name declared in include/i8ie_hip.h."""
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(i8ie_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libi8ie_hip.so not built: run python -m int8inferenceengine_amd.build")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.i8ie_last_error.restype = C.c_char_p
+        _lib.i8ie_ctx_stream.restype = C.c_void_p
+    return _lib
+
+
+class AbiError(RuntimeError):
+    pass
+
+
+def ck(rc):
+    if rc != 0:
+        raise AbiError("rc=%d: %s" % (rc, lib().i8ie_last_error().decode()))
+
+
+class Dev:
+    """A device buffer with shape/dtype bookkeeping."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx, self.shape, self.dtype = ctx, tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ptr = C.c_void_p()
+        ck(lib().i8ie_malloc(ctx.h, C.c_size_t(self.nbytes), C.byref(self.ptr)))
+
+    def get(self):
+        out = np.empty(self.shape, self.dtype)
+        ck(lib().i8ie_memcpy_d2h(self.ctx.h, out.ctypes.data_as(C.c_void_p), self.ptr, C.c_size_t(self.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().i8ie_free(self.ctx.h, self.ptr)
+            self.ptr = C.c_void_p()
+
+
+class Ctx:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        ck(lib().i8ie_ctx_create(device, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().i8ie_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def put(self, arr):
+        arr = np.ascontiguousarray(arr)
+        d = Dev(self, arr.shape, arr.dtype)
+        ck(lib().i8ie_memcpy_h2d(self.h, d.ptr, arr.ctypes.data_as(C.c_void_p), C.c_size_t(d.nbytes)))
+        return d
+
+    def empty(self, shape, dtype):
+        return Dev(self, shape, dtype)
+
+    def sync(self):
+        ck(lib().i8ie_sync(self.h))
+
+    # ---- ops ---------------------------------------------------------------
+    def quantize(self, x, scale, zp):
+        x = np.ascontiguousarray(x, np.float32)
+        d, o = self.put(x), self.empty(x.shape, np.uint8)
+        ck(lib().i8ie_quantize_f32_u8(self.h, d.ptr, o.ptr, C.c_int64(x.size), C.c_float(scale), C.c_uint8(zp)))
+        r = o.get()
+        d.free(); o.free()
+        return r
+
+    def dequantize(self, q, scale, zp):
+        q = np.ascontiguousarray(q, np.uint8)
+        d, o = self.put(q), self.empty(q.shape, np.float32)
+        ck(lib().i8ie_dequantize_u8_f32(self.h, d.ptr, o.ptr, C.c_int64(q.size), C.c_float(scale), C.c_uint8(zp)))
+        r = o.get()
+        d.free(); o.free()
+        return r
+
+    def down_scale(self, acc, sa, sb, sc, zp):
+        acc = np.ascontiguousarray(acc, np.int32)
+        d, o = self.put(acc), self.empty(acc.shape, np.uint8)
+        ck(lib().i8ie_down_scale(self.h, d.ptr, o.ptr, C.c_int64(acc.size), C.c_float(sa), C.c_float(sb),
+                                 C.c_float(sc), C.c_uint8(zp)))
+        r = o.get()
+        d.free(); o.free()
+        return r
+
+    def relu(self, q, zp):
+        q = np.ascontiguousarray(q, np.uint8)
+        d, o = self.put(q), self.empty(q.shape, np.uint8)
+        ck(lib().i8ie_relu_u8(self.h, d.ptr, o.ptr, C.c_int64(q.size), C.c_uint8(zp)))
+        r = o.get()
+        d.free(); o.free()
+        return r
+
+    def max_pool2d(self, q, k, s):
+        q = np.ascontiguousarray(q, np.uint8)
+        n, c, h, w = q.shape
+        oh, ow = (h - k) // s + 1, (w - k) // s + 1
+        d, o = self.put(q), self.empty((n, c, oh, ow), np.uint8)
+        ck(lib().i8ie_maxpool2d_u8(self.h, d.ptr, o.ptr, n, c, h, w, k, s))
+        r = o.get()
+        d.free(); o.free()
+        return r
+
+    def conv_offsets(self, qw, qb, s_in, zp_in):
+        qw = np.ascontiguousarray(qw, np.int8)
+        kc = qw.shape[0]
+        K = qw.size // kc
+        dw, db, o = self.put(qw), self.put(np.ascontiguousarray(qb, np.int8)), self.empty((kc,), np.int32)
+        ck(lib().i8ie_conv_offsets(self.h, dw.ptr, db.ptr, kc, K, C.c_float(s_in), C.c_uint8(zp_in), o.ptr))
+        r = o.get()
+        dw.free(); db.free(); o.free()
+        return r
+
+    def linear_offsets(self, qw, zp_in):
+        qw = np.ascontiguousarray(qw, np.int8)
+        n, k = qw.shape
+        dw, o = self.put(qw), self.empty((n,), np.int32)
+        ck(lib().i8ie_linear_offsets(self.h, dw.ptr, n, k, C.c_uint8(zp_in), o.ptr))
+        r = o.get()
+        dw.free(); o.free()
+        return r
+
+    def linear(self, q_in, qw, qb, s_in, zp_in, s_w, s_out, zp_out, want_acc=True):
+        """Stateless i8ie_linear_u8s8.  Returns (out, acc or None, oc)."""
+        q_in = np.ascontiguousarray(q_in, np.uint8)
+        qw = np.ascontiguousarray(qw, np.int8)
+        qb = np.ascontiguousarray(qb, np.int8)
+        m, k = q_in.shape
+        n = qw.shape[0]
+        di, dw, db = self.put(q_in), self.put(qw), self.put(qb)
+        oc = self.empty((n,), np.int32)
+        ck(lib().i8ie_linear_offsets(self.h, dw.ptr, n, k, C.c_uint8(zp_in), oc.ptr))
+        out = self.empty((m, n), np.uint8)
+        acc = self.empty((m, n), np.int32) if want_acc else None
+        ck(lib().i8ie_linear_u8s8(self.h, di.ptr, m, k, dw.ptr, db.ptr, n, oc.ptr, C.c_float(s_in), C.c_float(s_w),
+                                  C.c_float(s_out), C.c_uint8(zp_out), out.ptr, acc.ptr if acc else None))
+        r = (out.get(), acc.get() if acc else None, oc.get())
+        for b in (di, dw, db, oc, out, acc):
+            if b is not None:
+                b.free()
+        return r
+
+    def conv2d(self, q_in, qw, qb, stride, pad, s_in, zp_in, s_w, s_out, zp_out, want_acc=True):
+        """Stateless i8ie_conv2d_u8s8.  Returns (out NCHW, acc [n, oh*ow, kc] or None, oc)."""
+        q_in = np.ascontiguousarray(q_in, np.uint8)
+        qw = np.ascontiguousarray(qw, np.int8)
+        qb = np.ascontiguousarray(qb, np.int8)
+        n, c, h, w = q_in.shape
+        kc, _, kh, kw = qw.shape
+        oh, ow = (h - kh + 2 * pad) // stride + 1, (w - kw + 2 * pad) // stride + 1
+        di, dw, db = self.put(q_in), self.put(qw), self.put(qb)
+        oc = self.empty((kc,), np.int32)
+        ck(lib().i8ie_conv_offsets(self.h, dw.ptr, db.ptr, kc, c * kh * kw, C.c_float(s_in), C.c_uint8(zp_in), oc.ptr))
+        out = self.empty((n, kc, oh, ow), np.uint8)
+        acc = self.empty((n, oh * ow, kc), np.int32) if want_acc else None
+        ck(lib().i8ie_conv2d_u8s8(self.h, di.ptr, n, c, h, w, dw.ptr, kc, kh, kw, stride, pad, C.c_uint8(zp_in),
+                                  oc.ptr, C.c_float(s_in), C.c_float(s_w), C.c_float(s_out), C.c_uint8(zp_out),
+                                  out.ptr, acc.ptr if acc else None))
+        r = (out.get(), acc.get() if acc else None, oc.get())
+        for b in (di, dw, db, oc, out, acc):
+            if b is not None:
+                b.free()
+        return r
+
+    def layer_forward(self, kind, q_in, qw, qb, s_in, zp_in, s_w, s_out, zp_out, stride=1, pad=0, repeat=1,
+                      want_acc=True):
+        """Through the layer-handle API (i8ie_*_create / set_output_qparams / forward)."""
+        q_in = np.ascontiguousarray(q_in, np.uint8)
+        qw = np.ascontiguousarray(qw, np.int8)
+        qb = np.ascontiguousarray(qb, np.int8)
+        L = C.c_void_p()
+        if kind == "linear":
+            m, k = q_in.shape
+            n = qw.shape[0]
+            ck(lib().i8ie_linear_create(self.h, qw.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p), n, k,
+                                        C.c_float(s_w), C.byref(L)))
+            oshape, ashape, h, w = (m, n), (m, n), 0, 0
+        else:
+            m, c, h, w = q_in.shape
+            kc, _, kh, kw = qw.shape
+            oh, ow = (h - kh + 2 * pad) // stride + 1, (w - kw + 2 * pad) // stride + 1
+            ck(lib().i8ie_conv2d_create(self.h, qw.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p), kc, c,
+                                        kh, kw, stride, pad, C.c_float(s_w), C.byref(L)))
+            oshape, ashape = (m, kc, oh, ow), (m, oh * ow, kc)
+        ck(lib().i8ie_layer_set_output_qparams(L, C.c_float(s_out), C.c_uint8(zp_out)))
+        di = self.put(q_in)
+        out = self.empty(oshape, np.uint8)
+        acc = self.empty(ashape, np.int32) if want_acc else None
+        for _ in range(repeat):
+            ck(lib().i8ie_layer_forward(L, di.ptr, m, h, w, C.c_float(s_in), C.c_uint8(zp_in), out.ptr,
+                                        acc.ptr if acc else None))
+        r = (out.get(), acc.get() if acc else None)
+        lib().i8ie_layer_destroy(L)
+        for b in (di, out, acc):
+            if b is not None:
+                b.free()
+        return r

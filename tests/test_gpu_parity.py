@@ -1,0 +1,210 @@
+"""Parity of the HIP path against the oracle and the reference-derived golden
+vectors.  Everything here calls through the C-ABI (tests/abi.py, ctypes).
+Bar: bit-exact (integer / byte work; fp32 outputs compared as bit patterns)."""
+import numpy as np
+import pytest
+
+import abi
+import synth
+from conftest import load_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    c = abi.Ctx(0)
+    yield c
+    c.close()
+
+
+# ---------------------------------------------------------------- elementwise --
+def test_quantize_golden_and_oracle(gpu, orc):
+    for c in load_cases("ref_quantize.npz"):
+        assert np.array_equal(gpu.quantize(c["x"], float(c["par"][0]), int(c["par"][1])), c["q"])
+    rng = np.random.default_rng(0)
+    for n in (1, 15, 16, 17, 4097, 3 * 224 * 224 * 2 + 5):  # ragged tails around the 16-wide vector path
+        x = rng.uniform(-4, 4, n).astype(np.float32)
+        assert np.array_equal(gpu.quantize(x, 0.025, 127), orc.quantize(x, 0.025, 127))
+
+
+def test_dequantize_golden_and_oracle(gpu, orc):
+    for c in load_cases("ref_dequantize.npz"):
+        got = gpu.dequantize(c["q"], float(c["par"][0]), int(c["par"][1]))
+        assert np.array_equal(got.view(np.uint32), c["x"].view(np.uint32))
+    q = np.random.default_rng(1).integers(0, 256, 100003, dtype=np.uint8)
+    assert np.array_equal(gpu.dequantize(q, 0.0371, 9).view(np.uint32), orc.dequantize(q, 0.0371, 9).view(np.uint32))
+
+
+def test_down_scale_golden(gpu):
+    # the fp32 requantiser (src/quantize_utils.cc:27-36): IEEE divide, no contraction
+    for c in load_cases("ref_down_scale.npz"):
+        sa, sb, sc, zp = c["par"]
+        assert np.array_equal(gpu.down_scale(c["acc"], float(sa), float(sb), float(sc), int(zp)), c["out"])
+
+
+def test_relu_golden_and_oracle(gpu, orc):
+    for c in load_cases("ref_relu.npz"):
+        assert np.array_equal(gpu.relu(c["q"], int(c["par"][0])), c["out"])
+    q = np.random.default_rng(2).integers(0, 256, 96 * 55 * 55 + 7, dtype=np.uint8)
+    assert np.array_equal(gpu.relu(q, 131), orc.relu(q, 131))
+
+
+def test_maxpool_golden_and_oracle(gpu, orc):
+    for c in load_cases("ref_maxpool.npz"):
+        assert np.array_equal(gpu.max_pool2d(c["q"], int(c["par"][0]), int(c["par"][1])), c["out"])
+    q = np.random.default_rng(3).integers(0, 256, (3, 96, 55, 55), dtype=np.uint8)
+    assert np.array_equal(gpu.max_pool2d(q, 3, 2), orc.max_pool2d(q, 3, 2))
+
+
+# ---------------------------------------------------------------- offsets (a4) --
+def test_offset_vectors(gpu, orc):
+    rng = np.random.default_rng(4)
+    qw = rng.integers(-127, 128, (37, 363), dtype=np.int8)
+    qb = rng.integers(-127, 128, 37, dtype=np.int8)
+    assert np.array_equal(gpu.conv_offsets(qw, qb, np.float32(0.025), 127), orc.conv_offsets(qw, qb, 0.025, 127))
+    assert np.array_equal(gpu.linear_offsets(qw, 201), orc.linear_offsets(qw, 201))
+    # one-signed weights push the fp32 prefix sums past 2^24: the sequential fp32 order matters
+    qw = rng.integers(60, 128, (5, 9216), dtype=np.int8)
+    assert np.array_equal(gpu.linear_offsets(qw, 255), orc.linear_offsets(qw, 255))
+    assert np.array_equal(gpu.conv_offsets(qw, qb[:5], np.float32(0.01), 255), orc.conv_offsets(qw, qb[:5], 0.01, 255))
+
+
+# ---------------------------------------------------------------- Linear (a3) --
+LINEAR_SHAPES = [(1, 64, 1), (33, 64, 40), (4, 784, 10), (100, 784, 10), (7, 800, 500), (5, 500, 10), (3, 4096, 10),
+                 (130, 4096, 300), (64, 9216, 256), (257, 1040, 129)]
+
+
+@pytest.mark.parametrize("mkn", LINEAR_SHAPES)
+def test_linear_stateless_bit_exact(gpu, orc, mkn):
+    m, k, n = mkn
+    c = synth.linear_case(orc, 100 + m + k + n, m, k, n)
+    out, acc, oc = gpu.linear(c["q_in"], c["qw"], c["qb"], c["s_in"], c["zp_in"], c["s_w"], c["s_out"], c["zp_out"])
+    assert np.array_equal(oc, orc.linear_offsets(c["qw"], c["zp_in"]))
+    assert np.array_equal(acc, c["acc"])  # INT32 pre-requant accumulators
+    assert np.array_equal(out, c["out"])
+
+
+def test_linear_mfma_orientation(gpu, orc):
+    # A = "identity" rows with an asymmetric W: a transposed C/D map cannot pass
+    k = n = m = 64
+    q_in = np.zeros((m, k), np.uint8)
+    q_in[np.arange(m), np.arange(k)] = 1
+    qw = (np.arange(n)[:, None] * 2 - np.arange(k)[None, :]).clip(-127, 127).astype(np.int8)
+    qb = np.zeros(n, np.int8)
+    out, acc, _ = gpu.linear(q_in, qw, qb, 1.0, 0, 1.0, 1.0, 100)
+    assert np.array_equal(acc, qw.T.astype(np.int32))
+    want, _, _ = orc.linear(q_in, qw, qb, 1.0, 0, 1.0, 1.0, 100)
+    assert np.array_equal(out, want)
+
+
+def test_linear_extreme_values(gpu, orc):
+    rng = np.random.default_rng(9)
+    q_in = np.full((3, 9216), 255, np.uint8)
+    qw = np.full((4, 9216), -128, np.int8)
+    qw[1] = 127
+    qw[2] = rng.integers(-128, 128, 9216)
+    qb = np.array([127, -128, 5, 0], np.int8)
+    for zp_in in (0, 255):
+        out, acc, _ = gpu.linear(q_in, qw, qb, 0.02, zp_in, 0.001, 0.7, 128)
+        want, pre, _ = orc.linear(q_in, qw, qb, 0.02, zp_in, 0.001, 0.7, 128, want_acc=True)
+        assert np.array_equal(acc, pre) and np.array_equal(out, want)
+
+
+# ---------------------------------------------------------------- Conv2d (a2) --
+CONV_GEOMS = [
+    # n, c, h, w, kc, k, stride, pad
+    (2, 10, 22, 22, 20, 3, 1, 0), (2, 10, 22, 22, 20, 3, 1, 1), (2, 10, 50, 50, 20, 3, 7, 3),  # unittest/test_layers.py
+    (2, 3, 224, 224, 96, 11, 4, 2),   # AlexNet conv1
+    (2, 96, 27, 27, 256, 5, 1, 2),    # conv2
+    (3, 256, 13, 13, 384, 3, 1, 1),   # conv3
+    (2, 384, 13, 13, 384, 3, 1, 1),   # conv4
+    (2, 384, 13, 13, 256, 3, 1, 1),   # conv5
+    (3, 3, 32, 32, 20, 5, 1, 0), (3, 20, 28, 28, 50, 5, 1, 0), (3, 50, 12, 12, 120, 5, 1, 0),  # simple_conv
+    (4, 1, 28, 28, 20, 5, 1, 0), (4, 20, 12, 12, 50, 5, 1, 0),  # two_conv
+    (1, 1, 5, 5, 1, 5, 1, 0), (1, 2, 7, 9, 3, 3, 2, 2), (5, 7, 9, 6, 33, 1, 1, 0),  # degenerate / ragged
+]
+
+
+@pytest.mark.parametrize("geom", CONV_GEOMS)
+def test_conv2d_stateless_bit_exact(gpu, orc, geom):
+    n, c, h, w, kc, k, stride, pad = geom
+    cs = synth.conv_case(orc, 7 + sum(geom), n, c, h, w, kc, k, stride, pad)
+    out, acc, oc = gpu.conv2d(cs["q_in"], cs["qw"], cs["qb"], stride, pad, cs["s_in"], cs["zp_in"], cs["s_w"],
+                              cs["s_out"], cs["zp_out"])
+    assert np.array_equal(oc, orc.conv_offsets(cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"]))
+    assert np.array_equal(acc, cs["acc"])
+    assert np.array_equal(out, cs["out"])
+
+
+def test_conv2d_padding_uses_input_zero_point(gpu, orc):
+    # src/conv2d.cc:24-28: out-of-bounds taps read zero_point, not 0
+    for zp_in in (0, 3, 255):
+        cs = synth.conv_case(orc, 77 + zp_in, 2, 5, 9, 9, 8, 3, 1, 1, zp_in=zp_in)
+        out, acc, _ = gpu.conv2d(cs["q_in"], cs["qw"], cs["qb"], 1, 1, cs["s_in"], zp_in, cs["s_w"], cs["s_out"],
+                                 cs["zp_out"])
+        assert np.array_equal(acc, cs["acc"]) and np.array_equal(out, cs["out"])
+
+
+# ---------------------------------------------------------------- layer handles --
+def test_layer_handles_cache_offsets(gpu, orc):
+    cs = synth.conv_case(orc, 11, 3, 16, 13, 13, 24, 3, 1, 1)
+    out, acc = gpu.layer_forward("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
+                                 cs["s_out"], cs["zp_out"], stride=1, pad=1, repeat=3)
+    assert np.array_equal(acc, cs["acc"]) and np.array_equal(out, cs["out"])
+    ls = synth.linear_case(orc, 12, 50, 800, 500)
+    out, acc = gpu.layer_forward("linear", ls["q_in"], ls["qw"], ls["qb"], ls["s_in"], ls["zp_in"], ls["s_w"],
+                                 ls["s_out"], ls["zp_out"], repeat=2)
+    assert np.array_equal(acc, ls["acc"]) and np.array_equal(out, ls["out"])
+
+
+def test_layer_handle_rekeys_on_new_input_qparams(gpu, orc):
+    import ctypes as C
+
+    cs = synth.conv_case(orc, 13, 2, 8, 10, 10, 12, 3, 1, 1)
+    lib = abi.lib()
+    L = C.c_void_p()
+    abi.ck(lib.i8ie_conv2d_create(gpu.h, cs["qw"].ctypes.data_as(C.c_void_p), cs["qb"].ctypes.data_as(C.c_void_p), 12,
+                                  8, 3, 3, 1, 1, C.c_float(cs["s_w"]), C.byref(L)))
+    abi.ck(lib.i8ie_layer_set_output_qparams(L, C.c_float(cs["s_out"]), C.c_uint8(cs["zp_out"])))
+    di = gpu.put(cs["q_in"])
+    out = gpu.empty((2, 12, 10, 10), np.uint8)
+    for s_in, zp_in in ((0.025, 127), (0.05, 3), (0.025, 127)):
+        abi.ck(lib.i8ie_layer_forward(L, di.ptr, 2, 10, 10, C.c_float(s_in), C.c_uint8(zp_in), out.ptr, None))
+        want, _ = orc.conv2d(cs["q_in"], cs["qw"], cs["qb"], 1, 1, np.float32(s_in), zp_in, cs["s_w"], cs["s_out"],
+                             cs["zp_out"])
+        assert np.array_equal(out.get(), want)
+    lib.i8ie_layer_destroy(L)
+
+
+def test_argument_errors_are_reported(gpu):
+    import ctypes as C
+
+    lib = abi.lib()
+    d = gpu.empty((16,), np.uint8)
+    assert lib.i8ie_relu_u8(gpu.h, None, d.ptr, C.c_int64(16), C.c_uint8(0)) == -1
+    assert lib.i8ie_maxpool2d_u8(gpu.h, d.ptr, d.ptr, 1, 1, 4, 4, 5, 1) == -1  # window larger than input
+    L = C.c_void_p()
+    q = np.zeros(9, np.int8)
+    assert lib.i8ie_conv2d_create(gpu.h, q.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), 1, 1, 3, 3, 0, 0,
+                                  C.c_float(1), C.byref(L)) == -1  # stride 0 (include/conv2d.h:12-14)
+    assert b"stride" in lib.i8ie_last_error()
+
+
+# ---------------------------------------------------------------- batch invariance at full size --
+def test_conv_batch_invariance_at_bench_size(gpu, orc):
+    """BASELINE size (batch 1000, conv3 geometry): images are independent, so any
+    slice of the big batch must equal the same images run alone (and those are
+    oracle-checked).  Exercises the chunked im2col path and multi-image tiles."""
+    n = 1000
+    cs = synth.conv_case(orc, 21, 4, 256, 13, 13, 384, 3, 1, 1)
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 256, (n, 256, 13, 13), dtype=np.uint8)
+    big[:4] = cs["q_in"]
+    big[-4:] = cs["q_in"]
+    out, _ = gpu.layer_forward("conv", big, cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"], cs["s_out"],
+                               cs["zp_out"], stride=1, pad=1, want_acc=False)
+    assert np.array_equal(out[:4], cs["out"]) and np.array_equal(out[-4:], cs["out"])
+    mid, _ = gpu.layer_forward("conv", big[500:507], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
+                               cs["s_out"], cs["zp_out"], stride=1, pad=1, want_acc=False)
+    assert np.array_equal(out[500:507], mid)
