@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the INT8 hot path on MI355X.
+
+Workload (BASELINE.json configs[3]/[4]): AlexNet INT8, 224x224, global batch
+1000, random-init weights + synthetic inputs (the reference's checkpoints and
+CIFAR-10 are not available offline).  One "step" = the reference notebook's
+timed cell (sample/notebooks/AlexNet_cifar10_resize224.ipynb:212-218) for one
+batch: model(x) [quantize -> 5 conv / 3 fc INT8 layers with u8 relu / max-pool
+-> dequantize], logits to the host, argmax, compare with the labels.  Inputs
+are resident in HBM before the timed region (the notebook builds its tensors
+beforehand, :112-114).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU; the 1000 images shard contiguously over the ranks
+(strong scaling, as BASELINE.json configs[4] names it), each rank runs the full
+network on its shard and one RCCL all-gather collects the logits.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+INT8_DENSE_PEAK_TOPS = 5000.0  # MI355X dense int8 MFMA: 2x the ~2.5 PF bf16 rate (MI355X_MICROARCH.md, Matrix cores)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1000, help="global batch (images per step over all GPUs)")
+    ap.add_argument("--network", default="alexnet")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline sample")
+    ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs one process per GPU: launch with torch.distributed.run" % args.gpus)
+        args.gpus = world
+    use_dist = world > 1 or args.force_dist
+
+    import numpy as np
+
+    import torch  # first: libi8ie_hip.so must bind to the HIP runtime torch already loaded
+    import int8inferenceengine_amd  # noqa: F401
+    import _CXX_i8ie as cx
+    import i8ie
+    from int8inferenceengine_amd import sharding
+    from int8inferenceengine_amd import workloads as wl
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible (the INT8 path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if use_dist:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        # run our kernels on torch's current stream so the collective is stream-ordered behind them
+        cx.use_stream(torch.cuda.current_stream().cuda_stream, local_rank)
+    else:
+        cx.set_device(local_rank)
+
+    name = args.network
+    n_total = args.batch
+    start, stop = sharding.shard_bounds(n_total, rank, world)
+
+    # ---- model: the reference workflow, prepare -> one FP32 batch -> convert (identical on every rank)
+    sd = wl.synthetic_state_dict(name, seed=42)
+    net = wl.calibrated(name, sd)
+    qparams = {a: getattr(net, a).output_qparams() for a in wl.layer_names(name)}
+
+    # ---- inputs + FP32-teacher labels (centred argmax)
+    x_all = wl.synthetic_input(name, n_total, seed=1234)
+    x_loc = np.ascontiguousarray(x_all[start:stop])
+    fp32_net = wl.build(name)
+    fp32_net.load(sd)
+    centre = fp32_net(i8ie.tensor(wl.synthetic_input(name, 64, seed=4321))).numpy().mean(0)
+    lab_loc = sharding.centred_argmax(fp32_net(i8ie.tensor(x_loc)).numpy(), centre)
+    del fp32_net
+    cx.trim()
+    if use_dist:
+        lab_all = sharding.gather_rows(torch.from_numpy(lab_loc.astype(np.float32)[:, None]).cuda(), n_total)
+        lab_all = lab_all.cpu().numpy()[:, 0].astype(np.int64)
+    else:
+        lab_all = lab_loc
+
+    t_h2d0 = time.perf_counter()
+    x_dev = i8ie.tensor(x_loc).prefetch()  # resident in HBM before the timed region
+    cx.synchronize()
+    h2d_ms = (time.perf_counter() - t_h2d0) * 1e3
+    if use_dist:
+        stage = torch.empty((stop - start, 10), dtype=torch.float32, device="cuda")
+
+    state = {"correct": 0, "logits": None}
+
+    def step():
+        y = net(x_dev)  # quantize -> INT8 layers -> dequantize (all on the GPU, asynchronous)
+        if use_dist:
+            cx.copy_to_ptr(y.data, stage.data_ptr())
+            full = sharding.gather_rows(stage, n_total)
+            if rank == 0:
+                logits = full.cpu().numpy()
+        else:
+            logits = y.numpy()  # D2H (waits for the stream)
+        if rank == 0:
+            pred = sharding.centred_argmax(logits, centre)
+            state["correct"] = int((pred == lab_all).sum())
+            state["logits"] = logits
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    if rank == 0:
+        cx.profile_start()  # HIP events around every launch, on the stream the kernels run on
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = cx.profile_stop() if rank == 0 else {}
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_total * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (by device time) --------------------------------------
+    kernels = {k: {"launches": int(v[0]), "ms": v[1], "ops": v[2], "bytes": v[3]} for k, v in prof.items()}
+    mfma = {k: v for k, v in kernels.items() if v["ops"] > 0}
+    dom = max(mfma, key=lambda k: mfma[k]["ms"])
+    d = mfma[dom]
+    achieved = d["ops"] / (d["ms"] * 1e-3) / 1e12
+    roofline = {
+        "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": INT8_DENSE_PEAK_TOPS,
+        "unit": "TFLOP/s", "frac": round(achieved / INT8_DENSE_PEAK_TOPS, 4), "traffic": None,
+        "ops_per_launch": d["ops"] / d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+        "launches_per_step": d["launches"] / args.steps,
+    }
+    total_dev_ms = sum(v["ms"] for v in kernels.values())
+    breakdown = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
+    macs = wl.macs_per_image(name)
+    whole = {"int8_tops_whole_step": round(value * macs * 2 / 1e12, 2),
+             "frac_of_int8_peak_whole_step": round(value * macs * 2 / 1e12 / INT8_DENSE_PEAK_TOPS, 4),
+             "device_ms_per_step": round(total_dev_ms / args.steps, 3)}
+
+    # ---- CPU baseline: the oracle (C restatement of the reference algorithm) on the host cores --
+    cpu = None
+    parity = None
+    if world == 1 and not args.no_cpu_baseline:
+        import orc
+        import pipeline
+
+        # a 1-GPU box gives this job a 16-CPU share; libgomp is already initialised (torch), so set it by call
+        orc.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", min(len(os.sched_getaffinity(0)), 16))))
+
+        entry = wl.NETWORKS[name]
+        qlayers = pipeline.quantize_layers(entry, sd)
+        probe = min(8, n_total)
+        tp = time.perf_counter()
+        pipeline.forward(entry, x_all[:probe], qlayers, qparams)
+        rate = probe / (time.perf_counter() - tp)
+        sample = int(max(probe, min(n_total, rate * args.cpu_seconds)))
+        tp = time.perf_counter()
+        cap = {}
+        ref_logits = pipeline.forward(entry, x_all[:sample], qlayers, qparams, capture=cap)
+        cpu_s = time.perf_counter() - tp
+        cpu = {"value": round(sample / cpu_s, 2), "unit": "images/sec", "cores": orc.num_threads(), "kind": "port",
+               "sample": "%d of the %d images of the same batch, full network, %.1f s" % (sample, n_total, cpu_s),
+               "host": open("/proc/cpuinfo").read().split("model name")[1].split("\n")[0].strip(": \t")}
+        got = state["logits"][:sample]
+        t_gpu = float((sharding.centred_argmax(got, centre) == lab_all[:sample]).mean())
+        t_cpu = float((sharding.centred_argmax(ref_logits, centre) == lab_all[:sample]).mean())
+        parity = {"logits_bit_exact_vs_oracle": bool(np.array_equal(got.view(np.uint32), ref_logits.view(np.uint32))),
+                  "top1_vs_fp32_teacher_gpu": round(t_gpu, 4), "top1_vs_fp32_teacher_cpu_oracle": round(t_cpu, 4),
+                  "top1_delta": round(abs(t_gpu - t_cpu), 6), "images_compared": sample}
+
+    out = {
+        "metric": "images/sec AlexNet-INT8 224x224 bs=1000", "value": round(value, 1), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+        "config": {"workload": "%s INT8 forward + top-1, %dx%dx%d input, global batch %d sharded over %d GPU(s)"
+                   % ((name,) + wl.NETWORKS[name][2] + (n_total, world)),
+                   "global_batch": n_total, "per_gpu_batch": stop - start, "parallelism": "batch-shard x%d + logits all-gather" % world},
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "whole_step": whole,
+        "kernel_ms_per_step": breakdown, "top1_vs_fp32_teacher": round(state["correct"] / n_total, 4),
+        "h2d_ms_fp32_input": round(h2d_ms, 2),
+        "value_with_h2d": round(n_total / ((ms_per_step + h2d_ms) * 1e-3), 1),
+    }
+    print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,21 @@ int i8ie_ctx_destroy(i8ie_ctx* ctx);
 void* i8ie_ctx_stream(i8ie_ctx* ctx);   /* the hipStream_t, as void* */
 int i8ie_sync(i8ie_ctx* ctx);
 
+/* ---- per-kernel timing (measurement aid; nothing like it in the reference) ---
+ * Between start and stop every kernel launch of this ctx is bracketed by HIP
+ * events on the ctx's stream; stop waits for the stream and returns one entry
+ * per kernel name: launches, summed device time, summed algorithmic integer
+ * ops (2 x MACs, unpadded dimensions) and algorithmic bytes. */
+typedef struct i8ie_profile_entry {
+  char name[64];
+  uint64_t launches;
+  double total_ms;
+  double total_ops;
+  double total_bytes;
+} i8ie_profile_entry;
+int i8ie_profile_start(i8ie_ctx* ctx);
+int i8ie_profile_stop(i8ie_ctx* ctx, i8ie_profile_entry* entries, int max_entries, int* n_entries);
+
 /* ---- device memory (replaces `new T[]` + py::capsule, include/tensor.h:26-61) */
 /* Blocks come from a per-ctx caching allocator: i8ie_free() never blocks, and a freed
  * block may be handed to the next i8ie_malloc() at once.  That is safe because every

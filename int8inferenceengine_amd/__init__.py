@@ -18,6 +18,19 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 if _PKG_DIR not in sys.path:
     sys.path.insert(0, _PKG_DIR)
 
+# One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so and
+# libtorch_hip.so asks for it by the unversioned name, so if libi8ie_hip.so pulled
+# in /opt/rocm's libamdhip64.so.7 first, a later `import torch` would load a second
+# runtime and GPU initialisation would fail ("no ROCm-capable device").  Loading
+# torch first makes libi8ie_hip.so resolve libamdhip64.so.7 to torch's copy (same
+# SONAME), which also lets the two share device pointers, streams and RCCL.
+# Set I8IE_NO_TORCH_PRELOAD=1 for a torch-free process.
+if "torch" not in sys.modules and not os.environ.get("I8IE_NO_TORCH_PRELOAD"):
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
 
 def native_library_path():
     """Path of the C-ABI shared library (for ctypes / other FFI users)."""

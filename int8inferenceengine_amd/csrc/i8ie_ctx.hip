@@ -19,6 +19,39 @@ struct I8iePool {
   std::unordered_map<void*, size_t> live;        // block -> size
   size_t bytes_live = 0, bytes_cached = 0, n_hip_malloc = 0;
 };
+// ---- HIP-event profiler ---------------------------------------------------------
+#include <string>
+#include <vector>
+struct I8ieProfRec {
+  std::string name;
+  double ops, bytes;
+  hipEvent_t e0, e1;
+};
+struct I8ieProf {
+  std::vector<I8ieProfRec> recs;
+  std::vector<hipEvent_t> spare;
+};
+static hipEvent_t prof_event(I8ieProf* p) {
+  hipEvent_t e = nullptr;
+  if (!p->spare.empty()) {
+    e = p->spare.back();
+    p->spare.pop_back();
+  } else {
+    (void)hipEventCreate(&e);
+  }
+  return e;
+}
+void i8ie_prof_begin(i8ie_ctx* ctx, const char* name, double ops, double bytes) {
+  I8ieProf* p = static_cast<I8ieProf*>(ctx->prof);
+  I8ieProfRec r{name, ops, bytes, prof_event(p), prof_event(p)};
+  (void)hipEventRecord(r.e0, ctx->stream);
+  p->recs.push_back(r);
+}
+void i8ie_prof_end(i8ie_ctx* ctx) {
+  I8ieProf* p = static_cast<I8ieProf*>(ctx->prof);
+  (void)hipEventRecord(p->recs.back().e1, ctx->stream);
+}
+
 static inline I8iePool* pool_of(i8ie_ctx* c) { return static_cast<I8iePool*>(c->pool); }
 static inline size_t pool_round(size_t b) {
   if (b < 256) b = 256;
@@ -179,6 +212,46 @@ int i8ie_memory_stats(i8ie_ctx* ctx, size_t* bytes_live, size_t* bytes_cached, s
   if (bytes_live) *bytes_live = p->bytes_live;
   if (bytes_cached) *bytes_cached = p->bytes_cached + ctx->ws_bytes;
   if (n_device_allocs) *n_device_allocs = p->n_hip_malloc;
+  return I8IE_OK;
+}
+
+int i8ie_profile_start(i8ie_ctx* ctx) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  if (!ctx->prof) ctx->prof = new (std::nothrow) I8ieProf();
+  I8IE_REQUIRE(ctx->prof != nullptr, "out of host memory");
+  return I8IE_OK;
+}
+
+int i8ie_profile_stop(i8ie_ctx* ctx, i8ie_profile_entry* entries, int max_entries, int* n_entries) {
+  I8IE_REQUIRE(ctx != nullptr && n_entries != nullptr, "null argument");
+  *n_entries = 0;
+  if (!ctx->prof) return I8IE_OK;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  I8ieProf* p = static_cast<I8ieProf*>(ctx->prof);
+  std::map<std::string, i8ie_profile_entry> agg;
+  for (auto& r : p->recs) {
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    i8ie_profile_entry& e = agg[r.name];
+    if (e.launches == 0) {
+      memset(&e, 0, sizeof(e));
+      strncpy(e.name, r.name.c_str(), sizeof(e.name) - 1);
+    }
+    e.launches += 1;
+    e.total_ms += ms;
+    e.total_ops += r.ops;
+    e.total_bytes += r.bytes;
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  for (hipEvent_t e : p->spare) (void)hipEventDestroy(e);
+  delete p;
+  ctx->prof = nullptr;
+  for (auto& kv : agg) {
+    if (entries && *n_entries < max_entries) entries[*n_entries] = kv.second;
+    *n_entries += 1;
+  }
   return I8IE_OK;
 }
 

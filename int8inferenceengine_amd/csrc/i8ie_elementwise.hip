@@ -133,6 +133,7 @@ int i8ie_quantize_f32_u8(i8ie_ctx* ctx, const float* in, uint8_t* out, int64_t n
   I8IE_REQUIRE(aligned16(in) && aligned16(out), "buffers must be 16-byte aligned");
   if (n == 0) return I8IE_OK;
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8ieProfScope prof(ctx, "quantize_f32_u8", 0.0, 5.0 * n);
   quantize_kernel<<<grid_for((n >> 4) + 1), kThreads, 0, ctx->stream>>>(in, out, n, scale, (float)zp);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
@@ -144,6 +145,7 @@ int i8ie_dequantize_u8_f32(i8ie_ctx* ctx, const uint8_t* in, float* out, int64_t
   I8IE_REQUIRE(n >= 0, "negative size");
   if (n == 0) return I8IE_OK;
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8ieProfScope prof(ctx, "dequantize_u8_f32", 0.0, 5.0 * n);
   dequantize_kernel<<<grid_for(n), kThreads, 0, ctx->stream>>>(in, out, n, scale, (int)zp);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
@@ -155,6 +157,7 @@ int i8ie_down_scale(i8ie_ctx* ctx, const int32_t* acc, uint8_t* out, int64_t n, 
   I8IE_REQUIRE(n >= 0, "negative size");
   if (n == 0) return I8IE_OK;
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8ieProfScope prof(ctx, "down_scale", 0.0, 5.0 * n);
   down_scale_kernel<<<grid_for(n), kThreads, 0, ctx->stream>>>(acc, out, n, sa, sb, sc, (float)zp_c);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
@@ -167,6 +170,7 @@ int i8ie_relu_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int64_t n, uint
   if (n == 0) return I8IE_OK;
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
   uint32_t z = zp;
+  I8ieProfScope prof(ctx, "relu_u8", 0.0, 2.0 * n);
   relu_u8_kernel<<<grid_for((n >> 4) + 1), kThreads, 0, ctx->stream>>>(in, out, n,
                                                                         z | (z << 8) | (z << 16) | (z << 24));
   I8IE_LAUNCH_CHECK();
@@ -182,6 +186,7 @@ int i8ie_maxpool2d_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int
   int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
   int64_t total = (int64_t)n * c * oh * ow;
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8ieProfScope prof(ctx, "maxpool_u8_nchw", 0.0, (double)n * c * h * w + (double)total);
   maxpool_u8_nchw_kernel<<<grid_for(total), kThreads, 0, ctx->stream>>>(in, out, total, h, w, oh, ow,
                                                                        k, s);
   I8IE_LAUNCH_CHECK();

@@ -346,6 +346,10 @@ int launch_cfg(i8ie_ctx* ctx, const I8ieGemmArgs& a) {
   // walk the tile grid along the dimension whose operand panel is the larger one
   // to re-read: weights (N x K) vs activations (M x K)
   const int m_fastest = ((size_t)a.N > (size_t)a.M) ? 1 : 0;
+  static const char* kName = BN == 128 ? "gemm_u8s8_128x128" : BN == 96 ? "gemm_u8s8_128x96"
+                             : BN == 64 ? "gemm_u8s8_128x64" : "gemm_u8s8_128x32";
+  const double kt = a.Ktrue > 0 ? a.Ktrue : a.Kpad;
+  I8ieProfScope prof(ctx, kName, 2.0 * a.M * a.N * kt, (double)a.M * kt + (double)a.N * kt + (double)a.M * a.N);
   gemm_u8s8_kernel<WM, WN, TM, TN>
       <<<tiles_m * tiles_n, WM * WN * 64, 0, ctx->stream>>>(a, tiles_m, tiles_n, m_fastest);
   I8IE_LAUNCH_CHECK();
@@ -370,6 +374,7 @@ int i8ie_gemm_launch(i8ie_ctx* ctx, const I8ieGemmArgs& a) {
 int i8ie_launch_pad_rows(i8ie_ctx* ctx, const void* src, int rows, int k, void* dst, int rows_pad,
                          int k_pad, int fill) {
   const int64_t items = (int64_t)rows_pad * (k_pad >> 4);
+  I8ieProfScope prof(ctx, "pad_rows", 0.0, (double)rows * k + (double)rows_pad * k_pad);
   pad_rows_kernel<<<cap_grid(items, 256), 256, 0, ctx->stream>>>((const uint8_t*)src, rows, k, (uint8_t*)dst,
                                                                 rows_pad, k_pad, (uint32_t)(fill & 0xFF));
   I8IE_LAUNCH_CHECK();
@@ -379,6 +384,7 @@ int i8ie_launch_pad_rows(i8ie_ctx* ctx, const void* src, int rows, int k, void* 
 int i8ie_launch_offsets(i8ie_ctx* ctx, bool conv, const int8_t* qw, const int8_t* qb, int n, int K,
                         float s_in, int zp_in, int32_t* oc, int32_t* wsum) {
   const int grid = (n + 63) / 64;
+  I8ieProfScope prof(ctx, "offsets", 0.0, (double)n * K);
   if (conv)
     offsets_kernel<true><<<grid, 64, 0, ctx->stream>>>(qw, qb, n, K, s_in, zp_in, oc, wsum);
   else
@@ -390,6 +396,7 @@ int i8ie_launch_offsets(i8ie_ctx* ctx, bool conv, const int8_t* qw, const int8_t
 int i8ie_launch_im2col(i8ie_ctx* ctx, const uint8_t* in, uint8_t* col, int n, int c, int h, int w, int kh,
                        int kw, int oh, int ow, int stride, int pad, int K, int Kpad, int zp) {
   const int64_t rows = (int64_t)n * oh * ow;
+  I8ieProfScope prof(ctx, "im2col_u8_nchw", 0.0, (double)n * c * h * w + (double)rows * Kpad);
   im2col_u8_nchw_kernel<<<cap_grid(rows * (Kpad >> 4), 256), 256, 0, ctx->stream>>>(
       in, col, rows, c, h, w, kh, kw, oh, ow, stride, pad, K, Kpad, (uint32_t)zp);
   I8IE_LAUNCH_CHECK();

@@ -15,6 +15,21 @@ struct i8ie_ctx {
   void* ws = nullptr;  // scratch for one op at a time (stream-ordered reuse)
   size_t ws_bytes = 0;
   void* pool = nullptr;  // I8iePool* (i8ie_ctx.hip): stream-ordered caching allocator
+  void* prof = nullptr;  // I8ieProf* (i8ie_ctx.hip): HIP-event timing of every launch, when enabled
+};
+
+// Per-launch HIP-event timing on the ctx's stream (off unless i8ie_profile_start was
+// called).  `ops` = algorithmic integer ops (2 * MACs), `bytes` = algorithmic bytes.
+void i8ie_prof_begin(i8ie_ctx* ctx, const char* name, double ops, double bytes);
+void i8ie_prof_end(i8ie_ctx* ctx);
+struct I8ieProfScope {
+  i8ie_ctx* c;
+  I8ieProfScope(i8ie_ctx* ctx, const char* name, double ops, double bytes) : c(ctx) {
+    if (c->prof) i8ie_prof_begin(c, name, ops, bytes);
+  }
+  ~I8ieProfScope() {
+    if (c->prof) i8ie_prof_end(c);
+  }
 };
 
 void i8ie_set_error(const char* fmt, ...);
@@ -69,5 +84,6 @@ struct I8ieGemmArgs {
   int out_mode;  // I8IE_OUT_ROWMAJOR: out[M][N]; I8IE_OUT_NCHW: out[(img*N + j)*P + p], row = img*P + p
   int P;
   int32_t* acc;  // nullptr or [M][N]
+  int Ktrue;     // unpadded reduction length (profiling: algorithmic ops = 2*M*N*Ktrue)
 };
 int i8ie_gemm_launch(i8ie_ctx* ctx, const I8ieGemmArgs& a);

@@ -58,6 +58,7 @@ int linear_run(i8ie_ctx* ctx, const uint8_t* in, int m, int k, const int8_t* Bpa
   g.out_mode = I8IE_OUT_ROWMAJOR;
   g.P = 1;
   g.acc = acc;
+  g.Ktrue = k;
   return i8ie_gemm_launch(ctx, g);
 }
 
@@ -90,6 +91,7 @@ int conv_run(i8ie_ctx* ctx, const uint8_t* in, int n, const ConvGeom& cg, const 
     g.out_mode = I8IE_OUT_NCHW;
     g.P = P;
     g.acc = acc ? acc + (size_t)i0 * P * cg.kc : nullptr;
+    g.Ktrue = cg.K;
     I8IE_TRY(i8ie_gemm_launch(ctx, g));
   }
   return I8IE_OK;

@@ -623,6 +623,25 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
     return py::make_tuple(live, cached, allocs);
   });
   m.def("trim", []() { check(i8ie_trim(ctx())); });
+  m.def("profile_start", []() { check(i8ie_profile_start(ctx())); });
+  m.def("profile_stop", []() {
+    std::vector<i8ie_profile_entry> e(64);
+    int n = 0;
+    {
+      py::gil_scoped_release nogil;
+      check(i8ie_profile_stop(ctx(), e.data(), (int)e.size(), &n));
+    }
+    py::dict out;
+    for (int i = 0; i < n && i < (int)e.size(); ++i)
+      out[py::str(e[i].name)] = py::make_tuple(e[i].launches, e[i].total_ms, e[i].total_ops, e[i].total_bytes);
+    return out;
+  });
+  // run on a borrowed hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); call before the first op
+  m.def("use_stream", [](uintptr_t stream, int device) {
+    if (rt().ctx) throw std::runtime_error("i8ie: use_stream after the context was created");
+    rt().device = device;
+    check(i8ie_ctx_create_on_stream(device, (void*)stream, &rt().ctx));
+  });
   m.def("set_calibration_seed", [](long seed) { rt().calib_seed = seed; });
   // raw device copy into / out of foreign HIP memory (e.g. a torch tensor's data_ptr) for the
   // multi-GPU logits gather; both sides must be used on this module's stream or synchronised.

@@ -297,6 +297,15 @@ void orc_calib_range(float* samples /* [1000], sorted in place */, int64_t cnt,
   *zero_point = zp;
 }
 
+/* the host process may have initialised libgomp before OMP_NUM_THREADS could be set */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* number of OpenMP threads the baseline actually uses (bench.py reports it) */
 int orc_num_threads(void) {
 #ifdef _OPENMP

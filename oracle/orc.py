@@ -168,5 +168,9 @@ def calib_range(samples, cnt, quantile=1.0):
     return np.float32(scale.value), int(zp.value)
 
 
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
 def num_threads():
     return int(lib().orc_num_threads())
