@@ -51,6 +51,18 @@ int i8ie_ctx_destroy(i8ie_ctx* ctx);
 void* i8ie_ctx_stream(i8ie_ctx* ctx);   /* the hipStream_t, as void* */
 int i8ie_sync(i8ie_ctx* ctx);
 
+/* Options.  I8IE_OPT_FORCE_FALLBACK = 1 makes every layer handle take the any-geometry
+ * path (materialised im2col + v1 GEMM, separate ReLU) instead of the implicit-GEMM paths;
+ * results are identical, it exists so that tests can cover both. */
+#define I8IE_OPT_FORCE_FALLBACK 1
+int i8ie_ctx_set_option(i8ie_ctx* ctx, int option, int value);
+
+/* Activation layouts accepted by the *_fused / *_nhwc entry points.  NCHW is the
+ * reference's layout (include/tensor.h); NHWC is the engine's internal layout between
+ * layers (the reference's own GEMM output is HWC before its transpose, src/conv2d.cc:134-136). */
+#define I8IE_LAYOUT_NCHW 0
+#define I8IE_LAYOUT_NHWC 1
+
 /* ---- per-kernel timing (measurement aid; nothing like it in the reference) ---
  * Between start and stop every kernel launch of this ctx is bracketed by HIP
  * events on the ctx's stream; stop waits for the stream and returns one entry
@@ -164,7 +176,22 @@ int i8ie_layer_get_output_qparams(const i8ie_layer* layer, float* s_out, uint8_t
  * h, w are ignored for Linear.  acc_dbg_dev as in the stateless calls.       */
 int i8ie_layer_forward(i8ie_layer* layer, const uint8_t* in_dev, int m, int h, int w, float s_in,
                        uint8_t zp_in, uint8_t* out_dev, int32_t* acc_dbg_dev);
+/* Same computation with the layout conversions and the following relu<u8>
+ * (src/functional.cc:15-26: out = max(out, zp_out)) folded in.  in/out may each be NCHW or
+ * NHWC; i8ie_layer_preferred_layout tells which output layout avoids a conversion. */
+int i8ie_layer_forward_fused(i8ie_layer* layer, const uint8_t* in_dev, int in_layout, int m, int h, int w,
+                             float s_in, uint8_t zp_in, int relu, uint8_t* out_dev, int out_layout,
+                             int32_t* acc_dbg_dev);
+int i8ie_layer_preferred_layout(const i8ie_layer* layer, int* layout);
 int i8ie_layer_destroy(i8ie_layer* layer);
+
+/* ---- NHWC companions of the elementwise ops (internal layout between layers) ------------ */
+/* NCHW <-> NHWC of a u8 tensor [n,c,h,w] (to_nhwc != 0: NCHW -> NHWC) */
+int i8ie_layout_convert_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int n, int c, int h,
+                           int w, int to_nhwc);
+/* max_pool2d<u8_t> (src/functional.cc:36-64) on NHWC data, channels % 16 == 0 */
+int i8ie_maxpool2d_u8_nhwc(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int n, int c, int h,
+                           int w, int kernel_size, int stride);
 
 #ifdef __cplusplus
 }

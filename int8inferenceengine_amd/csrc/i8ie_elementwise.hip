@@ -78,8 +78,8 @@ __device__ __forceinline__ uint32_t max_u8x4(uint32_t a, uint32_t b) {
   return r;
 }
 
-__global__ __launch_bounds__(kThreads) void relu_u8_kernel(const uint8_t* __restrict__ in,
-                                                           uint8_t* __restrict__ out, int64_t n,
+__global__ __launch_bounds__(kThreads) void relu_u8_kernel(const uint8_t* in,  // may alias out (in-place)
+                                                           uint8_t* out, int64_t n,
                                                            uint32_t zp4) {
   const int64_t nvec = n >> 4;
   const int64_t stride = (int64_t)gridDim.x * kThreads;

@@ -16,6 +16,7 @@ struct i8ie_ctx {
   size_t ws_bytes = 0;
   void* pool = nullptr;  // I8iePool* (i8ie_ctx.hip): stream-ordered caching allocator
   void* prof = nullptr;  // I8ieProf* (i8ie_ctx.hip): HIP-event timing of every launch, when enabled
+  unsigned options = 0;  // bit 0: I8IE_OPT_FORCE_FALLBACK
 };
 
 // Per-launch HIP-event timing on the ctx's stream (off unless i8ie_profile_start was

@@ -1,77 +1,97 @@
 // i8ie_layer.hip -- Linear / Conv2d INT8 forward entry points of the C-ABI:
 // the stateless calls on raw device pointers and the layer handles that keep
-// the converted weights resident (packed for the MFMA kernel) and cache the
+// the converted weights resident (packed for the MFMA kernels) and cache the
 // zero-point offset vector per (s_in, zp_in).
 //   reference: src/fully_connected.cc:22-52, src/conv2d.cc:100-142,
 //              src/layer.cc:6-26,36-54
+//
+// Conv2d has three execution paths, all producing the reference's bytes:
+//   A  channels % 16 == 0: implicit GEMM over NHWC activations (i8ie_igemm.hip)
+//   B  channels <= 4 and stride % 4 == 0 (AlexNet conv1): the NCHW input is repacked
+//      once into a physically padded, 4-pixel-grouped NHWC image; then path A's kernel
+//   F  anything else: materialised im2col + v1 GEMM (i8ie_gemm.hip)
+// Activations cross the ABI as NCHW (the reference's layout) or, on request, as
+// NHWC so that consecutive layers skip the layout conversion.
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "i8ie_internal.h"
 
-int i8ie_launch_pad_rows(i8ie_ctx* ctx, const void* src, int rows, int k, void* dst, int rows_pad,
-                         int k_pad, int fill);
-int i8ie_launch_offsets(i8ie_ctx* ctx, bool conv, const int8_t* qw, const int8_t* qb, int n, int K,
-                        float s_in, int zp_in, int32_t* oc, int32_t* wsum);
-int i8ie_launch_im2col(i8ie_ctx* ctx, const uint8_t* in, uint8_t* col, int n, int c, int h, int w, int kh,
-                       int kw, int oh, int ow, int stride, int pad, int K, int Kpad, int zp);
+int i8ie_launch_pad_rows(i8ie_ctx* ctx, const void* src, int rows, int k, void* dst, int rows_pad, int k_pad,
+                         int fill);
+int i8ie_launch_offsets(i8ie_ctx* ctx, bool conv, const int8_t* qw, const int8_t* qb, int n, int K, float s_in,
+                        int zp_in, int32_t* oc, int32_t* wsum);
+int i8ie_launch_im2col(i8ie_ctx* ctx, const uint8_t* in, uint8_t* col, int n, int c, int h, int w, int kh, int kw,
+                       int oh, int ow, int stride, int pad, int K, int Kpad, int zp);
+int i8ie_launch_finish_offsets(i8ie_ctx* ctx, const int32_t* oc, const int32_t* wsum, const int8_t* qb, float s_in,
+                               int n, int32_t* ocp, float* biasf);
+int i8ie_launch_transpose_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int R, int S);
+int i8ie_launch_repack_smallc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int Hp,
+                              int Wg, int ph, int pw, int zp);
+int i8ie_launch_maxpool_nhwc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int k, int s);
+
+struct I8ieIgemmCall {
+  const uint8_t* A;
+  int amode;
+  long lda;
+  int M, Kchunks;
+  int H, W, C, KH, KW, sh, sw, ph, pw, OH, OW;
+  int zp_in;
+  const int8_t* B;
+  int Kpad, N;
+  const int32_t* ocp;
+  const float* biasf;
+  float s_in, s_w, s_out;
+  int zp_out, relu;
+  uint8_t* out;
+  int32_t* acc;
+  double Ktrue;
+};
+int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 
 namespace {
 
-constexpr size_t kColBudget = (size_t)192 << 20;  // im2col scratch per chunk: stays in the 256 MiB Infinity Cache
+constexpr size_t kColBudget = (size_t)192 << 20;  // im2col scratch per chunk (fallback path F)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+enum { PATH_F = 0, PATH_A = 1, PATH_B = 2 };
 
 struct ConvGeom {
   int c, h, w, kc, kh, kw, stride, pad, oh, ow, K, Kpad;
 };
 
-// Linear forward given packed weights.
-int linear_run(i8ie_ctx* ctx, const uint8_t* in, int m, int k, const int8_t* Bpack, int Kpad,
-               const int8_t* qb, int n, const int32_t* oc, const int32_t* wsum, float s_in, float s_w,
-               float s_out, uint8_t zp_out, uint8_t* out, int32_t* acc, uint8_t* scratch) {
-  I8ieGemmArgs g{};
-  if (k % 16 != 0 || !aligned16(in)) {
-    // ragged K: copy the activations into a 64-byte-padded image first
-    I8IE_TRY(i8ie_launch_pad_rows(ctx, in, m, k, scratch, m, Kpad, 0));
-    g.A = scratch;
-    g.lda = Kpad;
-    g.Ka = Kpad;
-  } else {
-    g.A = in;
-    g.lda = k;
-    g.Ka = k;
-  }
-  g.M = m;
-  g.B = Bpack;
-  g.Kpad = Kpad;
-  g.N = n;
-  g.oc = oc;
-  g.wsum = wsum;
-  g.qb = qb;
-  g.s_in = s_in;
-  g.s_w = s_w;
-  g.s_out = s_out;
-  g.zp_out = zp_out;
-  g.out = out;
-  g.out_mode = I8IE_OUT_ROWMAJOR;
-  g.P = 1;
-  g.acc = acc;
-  g.Ktrue = k;
-  return i8ie_gemm_launch(ctx, g);
+int conv_geom(int c, int h, int w, int kc, int kh, int kw, int stride, int pad, ConvGeom* g) {
+  I8IE_REQUIRE(c > 0 && h > 0 && w > 0 && kc > 0 && kh > 0 && kw > 0, "non-positive dimension");
+  I8IE_REQUIRE(stride > 0, "stride must be positive");  // include/conv2d.h:12-14
+  I8IE_REQUIRE(pad >= 0, "negative padding");
+  I8IE_REQUIRE(h - kh + 2 * pad >= 0 && w - kw + 2 * pad >= 0, "kernel larger than padded input");
+  g->c = c; g->h = h; g->w = w; g->kc = kc; g->kh = kh; g->kw = kw; g->stride = stride; g->pad = pad;
+  g->oh = (h - kh + 2 * pad) / stride + 1;  // src/conv2d.cc:108-109
+  g->ow = (w - kw + 2 * pad) / stride + 1;
+  g->K = c * kh * kw;
+  g->Kpad = round_up(g->K, 128);
+  return I8IE_OK;
 }
 
-// Conv forward given packed weights; the batch is processed in chunks whose
-// im2col image fits kColBudget.
-int conv_run(i8ie_ctx* ctx, const uint8_t* in, int n, const ConvGeom& cg, const int8_t* Bpack,
-             const int32_t* oc, const int32_t* wsum, uint8_t zp_in, float s_in, float s_w, float s_out,
-             uint8_t zp_out, uint8_t* out, int32_t* acc, uint8_t* col, int imgs_per_chunk) {
+inline int chunk_images(const ConvGeom& g, int n) {
+  const size_t per_img = (size_t)g.oh * g.ow * g.Kpad;
+  size_t imgs = kColBudget / per_img;
+  if (imgs < 1) imgs = 1;
+  return imgs > (size_t)n ? n : (int)imgs;
+}
+
+// ---- v1 (fallback) runners ------------------------------------------------------------------
+int conv_run_v1(i8ie_ctx* ctx, const uint8_t* in, int n, const ConvGeom& cg, const int8_t* Bpack, const int32_t* oc,
+                const int32_t* wsum, uint8_t zp_in, float s_in, float s_w, float s_out, uint8_t zp_out, uint8_t* out,
+                int32_t* acc, uint8_t* col, int imgs_per_chunk) {
   const int P = cg.oh * cg.ow;
   for (int i0 = 0; i0 < n; i0 += imgs_per_chunk) {
     const int nb = (n - i0) < imgs_per_chunk ? (n - i0) : imgs_per_chunk;
-    I8IE_TRY(i8ie_launch_im2col(ctx, in + (size_t)i0 * cg.c * cg.h * cg.w, col, nb, cg.c, cg.h, cg.w, cg.kh,
-                                cg.kw, cg.oh, cg.ow, cg.stride, cg.pad, cg.K, cg.Kpad, zp_in));
+    I8IE_TRY(i8ie_launch_im2col(ctx, in + (size_t)i0 * cg.c * cg.h * cg.w, col, nb, cg.c, cg.h, cg.w, cg.kh, cg.kw,
+                                cg.oh, cg.ow, cg.stride, cg.pad, cg.K, cg.Kpad, zp_in));
     I8ieGemmArgs g{};
     g.A = col;
     g.lda = cg.Kpad;
@@ -97,24 +117,24 @@ int conv_run(i8ie_ctx* ctx, const uint8_t* in, int n, const ConvGeom& cg, const 
   return I8IE_OK;
 }
 
-int conv_geom(int c, int h, int w, int kc, int kh, int kw, int stride, int pad, ConvGeom* g) {
-  I8IE_REQUIRE(c > 0 && h > 0 && w > 0 && kc > 0 && kh > 0 && kw > 0, "non-positive dimension");
-  I8IE_REQUIRE(stride > 0, "stride must be positive");  // include/conv2d.h:12-14
-  I8IE_REQUIRE(pad >= 0, "negative padding");
-  I8IE_REQUIRE(h - kh + 2 * pad >= 0 && w - kw + 2 * pad >= 0, "kernel larger than padded input");
-  g->c = c; g->h = h; g->w = w; g->kc = kc; g->kh = kh; g->kw = kw; g->stride = stride; g->pad = pad;
-  g->oh = (h - kh + 2 * pad) / stride + 1;  // src/conv2d.cc:108-109
-  g->ow = (w - kw + 2 * pad) / stride + 1;
-  g->K = c * kh * kw;
-  g->Kpad = round_up(g->K, 64);
-  return I8IE_OK;
-}
-
-inline int chunk_images(const ConvGeom& g, int n) {
-  const size_t per_img = (size_t)g.oh * g.ow * g.Kpad;
-  size_t imgs = kColBudget / per_img;
-  if (imgs < 1) imgs = 1;
-  return imgs > (size_t)n ? n : (int)imgs;
+int linear_run_v1(i8ie_ctx* ctx, const uint8_t* in, int m, int k, const int8_t* Bpack, int Kpad, const int8_t* qb,
+                  int n, const int32_t* oc, const int32_t* wsum, float s_in, float s_w, float s_out, uint8_t zp_out,
+                  uint8_t* out, int32_t* acc, uint8_t* scratch) {
+  I8ieGemmArgs g{};
+  if (k % 16 != 0 || !aligned16(in)) {
+    I8IE_TRY(i8ie_launch_pad_rows(ctx, in, m, k, scratch, m, Kpad, 0));
+    g.A = scratch;
+    g.lda = Kpad;
+    g.Ka = Kpad;
+  } else {
+    g.A = in;
+    g.lda = k;
+    g.Ka = k;
+  }
+  g.M = m; g.B = Bpack; g.Kpad = Kpad; g.N = n; g.oc = oc; g.wsum = wsum; g.qb = qb;
+  g.s_in = s_in; g.s_w = s_w; g.s_out = s_out; g.zp_out = zp_out;
+  g.out = out; g.out_mode = I8IE_OUT_ROWMAJOR; g.P = 1; g.acc = acc; g.Ktrue = k;
+  return i8ie_gemm_launch(ctx, g);
 }
 
 }  // namespace
@@ -122,26 +142,64 @@ inline int chunk_images(const ConvGeom& g, int n) {
 struct i8ie_layer {
   i8ie_ctx* ctx = nullptr;
   bool conv = false;
-  int n = 0, K = 0;  // out features, reduction length
+  int n = 0, K = 0;  // out features, reduction length (reference K order)
   int c = 0, kh = 0, kw = 0, stride = 1, pad = 0;
   int Kpad = 0, Npad = 0;
   float s_w = 1.0f;
   float s_out = 1.0f;   // include/layer.h:46
   uint8_t zp_out = 0;   // include/layer.h:47
-  int8_t* qw = nullptr;     // [n][K] as converted
+  int8_t* qw = nullptr;     // [n][K] as converted, K ordered (c, kh, kw)
   int8_t* qb = nullptr;     // [n]
-  int8_t* Bpack = nullptr;  // [Npad][Kpad], zero padded
+  int8_t* Bpack = nullptr;  // [Npad][Kpad] zero padded, reference K order (Linear; conv path F)
+  int path = PATH_F;        // conv: PATH_A / PATH_B / PATH_F
+  int8_t* Bpack2 = nullptr; // conv paths A/B: [Npad][Kpad2], K ordered (kh, kw, c) / grouped
+  int K2 = 0, Kpad2 = 0;    // valid / padded K of Bpack2 (bytes)
+  int kwg = 0;              // path B: taps per row in 4-pixel groups
   int32_t* wsum = nullptr;  // [n]
   int32_t* oc = nullptr;    // [n], valid for (oc_s_in, oc_zp_in)
+  int32_t* ocp = nullptr;   // [n] oc + 128 * wsum
+  float* biasf = nullptr;   // [n] (float)qb / s_in (Linear)
   bool oc_valid = false;
   float oc_s_in = 0.0f;
   int oc_zp_in = -1;
 };
 
+namespace {
+
+int ensure_offsets(i8ie_layer* L, float s_in, uint8_t zp_in) {
+  uint32_t a, b;
+  memcpy(&a, &s_in, 4);
+  memcpy(&b, &L->oc_s_in, 4);
+  if (L->oc_valid && L->oc_zp_in == (int)zp_in && a == b) return I8IE_OK;
+  // the reference recomputes this on every call (src/conv2d.cc:117-124); it only depends on
+  // (s_in, zp_in), which are fixed once the network is converted
+  i8ie_ctx* ctx = L->ctx;
+  I8IE_TRY(i8ie_launch_offsets(ctx, L->conv, L->qw, L->qb, L->n, L->K, s_in, zp_in, L->oc, nullptr));
+  I8IE_TRY(i8ie_launch_finish_offsets(ctx, L->oc, L->wsum, L->qb, s_in, L->n, L->ocp, L->conv ? nullptr : L->biasf));
+  L->oc_valid = true;
+  L->oc_s_in = s_in;
+  L->oc_zp_in = zp_in;
+  return I8IE_OK;
+}
+
+bool force_fallback(const i8ie_ctx* ctx) { return (ctx->options & 1) != 0; }
+
+}  // namespace
+
 extern "C" {
 
-int i8ie_conv_offsets(i8ie_ctx* ctx, const int8_t* qw, const int8_t* qb, int kc, int K, float s_in,
-                      uint8_t zp_in, int32_t* oc) {
+int i8ie_ctx_set_option(i8ie_ctx* ctx, int option, int value) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  I8IE_REQUIRE(option == I8IE_OPT_FORCE_FALLBACK, "unknown option");
+  if (value)
+    ctx->options |= 1;
+  else
+    ctx->options &= ~1;
+  return I8IE_OK;
+}
+
+int i8ie_conv_offsets(i8ie_ctx* ctx, const int8_t* qw, const int8_t* qb, int kc, int K, float s_in, uint8_t zp_in,
+                      int32_t* oc) {
   I8IE_REQUIRE(ctx && qw && qb && oc, "null argument");
   I8IE_REQUIRE(kc > 0 && K > 0, "non-positive dimension");
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
@@ -155,13 +213,14 @@ int i8ie_linear_offsets(i8ie_ctx* ctx, const int8_t* qw, int n, int k, uint8_t z
   return i8ie_launch_offsets(ctx, false, qw, nullptr, n, k, 0.0f, zp_in, oc, nullptr);
 }
 
-int i8ie_linear_u8s8(i8ie_ctx* ctx, const uint8_t* in, int m, int k, const int8_t* qw, const int8_t* qb,
-                     int n, const int32_t* oc, float s_in, float s_w, float s_out, uint8_t zp_out,
-                     uint8_t* out, int32_t* acc) {
+// ---- stateless entry points: any geometry, v1 kernels, caller supplies oc --------------------
+int i8ie_linear_u8s8(i8ie_ctx* ctx, const uint8_t* in, int m, int k, const int8_t* qw, const int8_t* qb, int n,
+                     const int32_t* oc, float s_in, float s_w, float s_out, uint8_t zp_out, uint8_t* out,
+                     int32_t* acc) {
   I8IE_REQUIRE(ctx && in && qw && qb && oc && out, "null argument");
   I8IE_REQUIRE(m > 0 && k > 0 && n > 0, "non-positive dimension");
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
-  const int Kpad = round_up(k, 64), Npad = round_up(n, 128);
+  const int Kpad = round_up(k, 128), Npad = round_up(n, 128);
   const size_t b_bytes = i8ie_align_up((size_t)Npad * Kpad, 256);
   const size_t s_bytes = i8ie_align_up((size_t)n * 4, 256);
   const size_t a_bytes = (size_t)m * Kpad;
@@ -172,12 +231,12 @@ int i8ie_linear_u8s8(i8ie_ctx* ctx, const uint8_t* in, int m, int k, const int8_
   uint8_t* scratch = ws + b_bytes + s_bytes;
   I8IE_TRY(i8ie_launch_pad_rows(ctx, qw, n, k, Bpack, Npad, Kpad, 0));
   I8IE_TRY(i8ie_launch_offsets(ctx, false, qw, nullptr, n, k, 0.0f, 0, nullptr, wsum));
-  return linear_run(ctx, in, m, k, Bpack, Kpad, qb, n, oc, wsum, s_in, s_w, s_out, zp_out, out, acc, scratch);
+  return linear_run_v1(ctx, in, m, k, Bpack, Kpad, qb, n, oc, wsum, s_in, s_w, s_out, zp_out, out, acc, scratch);
 }
 
-int i8ie_conv2d_u8s8(i8ie_ctx* ctx, const uint8_t* in, int n, int c, int h, int w, const int8_t* qw, int kc,
-                     int kh, int kw, int stride, int pad, uint8_t zp_in, const int32_t* oc, float s_in,
-                     float s_w, float s_out, uint8_t zp_out, uint8_t* out, int32_t* acc) {
+int i8ie_conv2d_u8s8(i8ie_ctx* ctx, const uint8_t* in, int n, int c, int h, int w, const int8_t* qw, int kc, int kh,
+                     int kw, int stride, int pad, uint8_t zp_in, const int32_t* oc, float s_in, float s_w,
+                     float s_out, uint8_t zp_out, uint8_t* out, int32_t* acc) {
   I8IE_REQUIRE(ctx && in && qw && oc && out, "null argument");
   I8IE_REQUIRE(n > 0, "non-positive batch");
   ConvGeom cg;
@@ -195,12 +254,32 @@ int i8ie_conv2d_u8s8(i8ie_ctx* ctx, const uint8_t* in, int n, int c, int h, int 
   uint8_t* col = ws + b_bytes + s_bytes;
   I8IE_TRY(i8ie_launch_pad_rows(ctx, qw, kc, cg.K, Bpack, Npad, cg.Kpad, 0));
   I8IE_TRY(i8ie_launch_offsets(ctx, true, qw, nullptr, kc, cg.K, 1.0f, 0, nullptr, wsum));
-  return conv_run(ctx, in, n, cg, Bpack, oc, wsum, zp_in, s_in, s_w, s_out, zp_out, out, acc, col, ipc);
+  return conv_run_v1(ctx, in, n, cg, Bpack, oc, wsum, zp_in, s_in, s_w, s_out, zp_out, out, acc, col, ipc);
 }
 
-// ---- layer handles -------------------------------------------------------------
-static int layer_create(i8ie_ctx* ctx, bool conv, const int8_t* qw_host, const int8_t* qb_host, int n, int K,
-                        int c, int kh, int kw, int stride, int pad, float s_w, i8ie_layer** out) {
+// ---- NHWC helpers exposed on the ABI -----------------------------------------------------------
+int i8ie_layout_convert_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int to_nhwc) {
+  I8IE_REQUIRE(ctx && in && out, "null argument");
+  I8IE_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, "non-positive dimension");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  if (to_nhwc) return i8ie_launch_transpose_u8(ctx, in, out, n, c, h * w);
+  return i8ie_launch_transpose_u8(ctx, in, out, n, h * w, c);
+}
+
+int i8ie_maxpool2d_u8_nhwc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int k, int s) {
+  I8IE_REQUIRE(ctx && in && out, "null argument");
+  I8IE_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, "non-positive dimension");
+  I8IE_REQUIRE(c % 16 == 0, "NHWC max-pool needs channels % 16 == 0");
+  I8IE_REQUIRE(k > 0 && s > 0, "kernel_size and stride must be positive");
+  I8IE_REQUIRE(k <= h && k <= w, "window larger than the input");
+  I8IE_REQUIRE(aligned16(in) && aligned16(out), "buffers must be 16-byte aligned");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  return i8ie_launch_maxpool_nhwc(ctx, in, out, n, c, h, w, k, s);
+}
+
+// ---- layer handles ----------------------------------------------------------------------------
+static int layer_create(i8ie_ctx* ctx, bool conv, const int8_t* qw_host, const int8_t* qb_host, int n, int K, int c,
+                        int kh, int kw, int stride, int pad, float s_w, i8ie_layer** out) {
   I8IE_REQUIRE(ctx && qw_host && qb_host && out, "null argument");
   I8IE_REQUIRE(n > 0 && K > 0, "non-positive dimension");
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
@@ -208,8 +287,33 @@ static int layer_create(i8ie_ctx* ctx, bool conv, const int8_t* qw_host, const i
   if (!L) return I8IE_ERR_OOM;
   L->ctx = ctx; L->conv = conv; L->n = n; L->K = K; L->c = c; L->kh = kh; L->kw = kw;
   L->stride = stride; L->pad = pad; L->s_w = s_w;
-  L->Kpad = round_up(K, 64);
+  L->Kpad = round_up(K, 128);
   L->Npad = round_up(n, 128);
+  // MFMA-order weight panel for the implicit-GEMM conv paths, built on the host once
+  std::vector<int8_t> pack2;
+  if (conv && c % 16 == 0) {
+    L->path = PATH_A;
+    L->K2 = kh * kw * c;
+    L->Kpad2 = round_up(L->K2, 128);
+    pack2.assign((size_t)L->Npad * L->Kpad2, 0);
+    for (int j = 0; j < n; ++j)
+      for (int ch = 0; ch < c; ++ch)
+        for (int y = 0; y < kh; ++y)
+          for (int x = 0; x < kw; ++x)
+            pack2[(size_t)j * L->Kpad2 + ((size_t)y * kw + x) * c + ch] = qw_host[(((size_t)j * c + ch) * kh + y) * kw + x];
+  } else if (conv && c <= 4 && stride % 4 == 0) {
+    L->path = PATH_B;
+    L->kwg = (kw + 3) / 4;
+    L->K2 = kh * L->kwg * 16;
+    L->Kpad2 = round_up(L->K2, 128);
+    pack2.assign((size_t)L->Npad * L->Kpad2, 0);
+    for (int j = 0; j < n; ++j)
+      for (int ch = 0; ch < c; ++ch)
+        for (int y = 0; y < kh; ++y)
+          for (int x = 0; x < kw; ++x)
+            pack2[(size_t)j * L->Kpad2 + ((size_t)y * L->kwg + x / 4) * 16 + (x % 4) * 4 + ch] =
+                qw_host[(((size_t)j * c + ch) * kh + y) * kw + x];
+  }
   int rc = I8IE_OK;
   do {
     if ((rc = i8ie_malloc(ctx, (size_t)n * K, (void**)&L->qw)) != I8IE_OK) break;
@@ -217,10 +321,16 @@ static int layer_create(i8ie_ctx* ctx, bool conv, const int8_t* qw_host, const i
     if ((rc = i8ie_malloc(ctx, (size_t)L->Npad * L->Kpad, (void**)&L->Bpack)) != I8IE_OK) break;
     if ((rc = i8ie_malloc(ctx, (size_t)n * 4, (void**)&L->wsum)) != I8IE_OK) break;
     if ((rc = i8ie_malloc(ctx, (size_t)n * 4, (void**)&L->oc)) != I8IE_OK) break;
+    if ((rc = i8ie_malloc(ctx, (size_t)n * 4, (void**)&L->ocp)) != I8IE_OK) break;
+    if ((rc = i8ie_malloc(ctx, (size_t)n * 4, (void**)&L->biasf)) != I8IE_OK) break;
     if ((rc = i8ie_memcpy_h2d(ctx, L->qw, qw_host, (size_t)n * K)) != I8IE_OK) break;
     if ((rc = i8ie_memcpy_h2d(ctx, L->qb, qb_host, (size_t)n)) != I8IE_OK) break;
     if ((rc = i8ie_launch_pad_rows(ctx, L->qw, n, K, L->Bpack, L->Npad, L->Kpad, 0)) != I8IE_OK) break;
     if ((rc = i8ie_launch_offsets(ctx, conv, L->qw, nullptr, n, K, 1.0f, 0, nullptr, L->wsum)) != I8IE_OK) break;
+    if (!pack2.empty()) {
+      if ((rc = i8ie_malloc(ctx, pack2.size(), (void**)&L->Bpack2)) != I8IE_OK) break;
+      if ((rc = i8ie_memcpy_h2d(ctx, L->Bpack2, pack2.data(), pack2.size())) != I8IE_OK) break;
+    }
   } while (0);
   if (rc != I8IE_OK) {
     i8ie_layer_destroy(L);
@@ -235,8 +345,8 @@ int i8ie_linear_create(i8ie_ctx* ctx, const int8_t* qw_host, const int8_t* qb_ho
   return layer_create(ctx, false, qw_host, qb_host, n, k, 0, 0, 0, 1, 0, s_w, out);
 }
 
-int i8ie_conv2d_create(i8ie_ctx* ctx, const int8_t* qw_host, const int8_t* qb_host, int kc, int c, int kh,
-                       int kw, int stride, int pad, float s_w, i8ie_layer** out) {
+int i8ie_conv2d_create(i8ie_ctx* ctx, const int8_t* qw_host, const int8_t* qb_host, int kc, int c, int kh, int kw,
+                       int stride, int pad, float s_w, i8ie_layer** out) {
   I8IE_REQUIRE(c > 0 && kh > 0 && kw > 0, "non-positive dimension");
   I8IE_REQUIRE(stride > 0, "stride must be positive");
   I8IE_REQUIRE(pad >= 0, "negative padding");
@@ -257,35 +367,128 @@ int i8ie_layer_get_output_qparams(const i8ie_layer* L, float* s_out, uint8_t* zp
   return I8IE_OK;
 }
 
-int i8ie_layer_forward(i8ie_layer* L, const uint8_t* in, int m, int h, int w, float s_in, uint8_t zp_in,
-                       uint8_t* out, int32_t* acc) {
+int i8ie_layer_preferred_layout(const i8ie_layer* L, int* layout) {
+  I8IE_REQUIRE(L && layout, "null argument");
+  const bool fast = L->conv && L->path != PATH_F && !force_fallback(L->ctx) && (L->n % 16 == 0);
+  *layout = fast ? I8IE_LAYOUT_NHWC : I8IE_LAYOUT_NCHW;
+  return I8IE_OK;
+}
+
+int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, int m, int h, int w, float s_in,
+                             uint8_t zp_in, int relu, uint8_t* out, int out_layout, int32_t* acc) {
   I8IE_REQUIRE(L && in && out, "null argument");
   I8IE_REQUIRE(m > 0, "non-positive batch");
+  I8IE_REQUIRE((in_layout == I8IE_LAYOUT_NCHW || in_layout == I8IE_LAYOUT_NHWC) &&
+                   (out_layout == I8IE_LAYOUT_NCHW || out_layout == I8IE_LAYOUT_NHWC),
+               "bad layout tag");
   i8ie_ctx* ctx = L->ctx;
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
-  uint32_t sb_new, sb_old;
-  memcpy(&sb_new, &s_in, 4);
-  memcpy(&sb_old, &L->oc_s_in, 4);
-  if (!L->oc_valid || L->oc_zp_in != (int)zp_in || (L->conv && sb_new != sb_old)) {
-    // the reference recomputes this on every call (src/conv2d.cc:117-124); it only
-    // depends on (s_in, zp_in), which are fixed once the network is converted
-    I8IE_TRY(i8ie_launch_offsets(ctx, L->conv, L->qw, L->qb, L->n, L->K, s_in, zp_in, L->oc, nullptr));
-    L->oc_valid = true;
-    L->oc_s_in = s_in;
-    L->oc_zp_in = zp_in;
-  }
-  if (!L->conv) {
+  I8IE_TRY(ensure_offsets(L, s_in, zp_in));
+
+  if (!L->conv) {  // ---- Linear: row-major in / out, layouts do not apply -----------------------
     const bool need_pad = (L->K % 16 != 0) || !aligned16(in);
-    if (need_pad) I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->Kpad));
-    return linear_run(ctx, in, m, L->K, L->Bpack, L->Kpad, L->qb, L->n, L->oc, L->wsum, s_in, L->s_w,
-                      L->s_out, L->zp_out, out, acc, (uint8_t*)ctx->ws);
+    if (force_fallback(ctx)) {
+      if (need_pad) I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->Kpad));
+      I8IE_TRY(linear_run_v1(ctx, in, m, L->K, L->Bpack, L->Kpad, L->qb, L->n, L->oc, L->wsum, s_in, L->s_w, L->s_out,
+                             L->zp_out, out, acc, (uint8_t*)ctx->ws));
+      if (relu) I8IE_TRY(i8ie_relu_u8(ctx, out, out, (int64_t)m * L->n, L->zp_out));
+      return I8IE_OK;
+    }
+    I8ieIgemmCall c{};
+    if (need_pad) {
+      I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->Kpad));
+      I8IE_TRY(i8ie_launch_pad_rows(ctx, in, m, L->K, ctx->ws, m, L->Kpad, 0));
+      c.A = (const uint8_t*)ctx->ws;
+      c.lda = L->Kpad;
+      c.Kchunks = L->Kpad / 16;
+    } else {
+      c.A = in;
+      c.lda = L->K;
+      c.Kchunks = L->K / 16;
+    }
+    c.amode = 0; c.M = m; c.zp_in = zp_in;
+    c.B = L->Bpack; c.Kpad = L->Kpad; c.N = L->n; c.ocp = L->ocp; c.biasf = L->biasf;
+    c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
+    c.out = out; c.acc = acc; c.Ktrue = L->K;
+    return i8ie_igemm_launch(ctx, c);
   }
+
+  // ---- Conv2d --------------------------------------------------------------------------------
   ConvGeom cg;
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
-  const int ipc = chunk_images(cg, m);
-  I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)ipc * cg.oh * cg.ow * cg.Kpad));
-  return conv_run(ctx, in, m, cg, L->Bpack, L->oc, L->wsum, zp_in, s_in, L->s_w, L->s_out, L->zp_out, out,
-                  acc, (uint8_t*)ctx->ws, ipc);
+  const size_t in_bytes = (size_t)m * cg.c * cg.h * cg.w;
+  const size_t out_bytes = (size_t)m * cg.kc * cg.oh * cg.ow;
+  const int path = force_fallback(ctx) ? PATH_F : L->path;
+
+  if (path == PATH_F) {
+    const int ipc = chunk_images(cg, m);
+    const size_t col_bytes = i8ie_align_up((size_t)ipc * cg.oh * cg.ow * cg.Kpad, 256);
+    const size_t a_bytes = in_layout == I8IE_LAYOUT_NHWC ? i8ie_align_up(in_bytes, 256) : 0;
+    const size_t o_bytes = out_layout == I8IE_LAYOUT_NHWC ? i8ie_align_up(out_bytes, 256) : 0;
+    I8IE_TRY(i8ie_ws_reserve(ctx, col_bytes + a_bytes + o_bytes));
+    uint8_t* ws = (uint8_t*)ctx->ws;
+    uint8_t* col = ws;
+    const uint8_t* src = in;
+    if (a_bytes) {
+      I8IE_TRY(i8ie_launch_transpose_u8(ctx, in, ws + col_bytes, m, cg.h * cg.w, cg.c));
+      src = ws + col_bytes;
+    }
+    uint8_t* dst = o_bytes ? ws + col_bytes + a_bytes : out;
+    I8IE_TRY(conv_run_v1(ctx, src, m, cg, L->Bpack, L->oc, L->wsum, zp_in, s_in, L->s_w, L->s_out, L->zp_out, dst, acc,
+                         col, ipc));
+    if (relu) I8IE_TRY(i8ie_relu_u8(ctx, dst, dst, (int64_t)out_bytes, L->zp_out));
+    if (o_bytes) I8IE_TRY(i8ie_launch_transpose_u8(ctx, dst, out, m, cg.kc, cg.oh * cg.ow));
+    return I8IE_OK;
+  }
+
+  I8ieIgemmCall c{};
+  c.amode = 1; c.M = m * cg.oh * cg.ow; c.zp_in = zp_in;
+  c.B = L->Bpack2; c.Kpad = L->Kpad2; c.Kchunks = L->K2 / 16; c.N = L->n; c.ocp = L->ocp; c.biasf = nullptr;
+  c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
+  c.acc = acc; c.Ktrue = cg.K; c.OH = cg.oh; c.OW = cg.ow;
+  const size_t o_bytes = out_layout == I8IE_LAYOUT_NCHW ? i8ie_align_up(out_bytes, 256) : 0;
+
+  if (path == PATH_A) {
+    const size_t a_bytes = in_layout == I8IE_LAYOUT_NCHW ? i8ie_align_up(in_bytes, 256) : 0;
+    I8IE_TRY(i8ie_ws_reserve(ctx, a_bytes + o_bytes + 256));
+    uint8_t* ws = (uint8_t*)ctx->ws;
+    if (a_bytes) {
+      I8IE_TRY(i8ie_launch_transpose_u8(ctx, in, ws, m, cg.c, cg.h * cg.w));
+      c.A = ws;
+    } else {
+      I8IE_REQUIRE(aligned16(in), "NHWC input must be 16-byte aligned");
+      c.A = in;
+    }
+    c.H = cg.h; c.W = cg.w; c.C = cg.c; c.KH = cg.kh; c.KW = cg.kw;
+    c.sh = c.sw = cg.stride; c.ph = c.pw = cg.pad;
+    c.out = o_bytes ? ws + a_bytes : out;
+  } else {  // PATH_B: small-C, stride % 4 == 0
+    const int Hp = (cg.oh - 1) * cg.stride + cg.kh;
+    const int Wg = (cg.ow - 1) * (cg.stride / 4) + L->kwg;
+    const size_t t_bytes = in_layout == I8IE_LAYOUT_NHWC ? i8ie_align_up(in_bytes, 256) : 0;
+    const size_t r_bytes = i8ie_align_up((size_t)m * Hp * Wg * 16, 256);
+    I8IE_TRY(i8ie_ws_reserve(ctx, t_bytes + r_bytes + o_bytes + 256));
+    uint8_t* ws = (uint8_t*)ctx->ws;
+    const uint8_t* src = in;
+    if (t_bytes) {
+      I8IE_TRY(i8ie_launch_transpose_u8(ctx, in, ws, m, cg.h * cg.w, cg.c));
+      src = ws;
+    }
+    uint8_t* rep = ws + t_bytes;
+    I8IE_TRY(i8ie_launch_repack_smallc(ctx, src, rep, m, cg.c, cg.h, cg.w, Hp, Wg, cg.pad, cg.pad, zp_in));
+    c.A = rep;
+    c.H = Hp; c.W = Wg; c.C = 16; c.KH = cg.kh; c.KW = L->kwg;
+    c.sh = cg.stride; c.sw = cg.stride / 4; c.ph = c.pw = 0;
+    c.out = o_bytes ? ws + t_bytes + r_bytes : out;
+  }
+  I8IE_TRY(i8ie_igemm_launch(ctx, c));
+  if (o_bytes) I8IE_TRY(i8ie_launch_transpose_u8(ctx, c.out, out, m, cg.oh * cg.ow, cg.kc));
+  return I8IE_OK;
+}
+
+int i8ie_layer_forward(i8ie_layer* L, const uint8_t* in, int m, int h, int w, float s_in, uint8_t zp_in, uint8_t* out,
+                       int32_t* acc) {
+  return i8ie_layer_forward_fused(L, in, I8IE_LAYOUT_NCHW, m, h, w, s_in, zp_in, 0, out, I8IE_LAYOUT_NCHW, acc);
 }
 
 int i8ie_layer_destroy(i8ie_layer* L) {
@@ -294,8 +497,11 @@ int i8ie_layer_destroy(i8ie_layer* L) {
   i8ie_free(ctx, L->qw);
   i8ie_free(ctx, L->qb);
   i8ie_free(ctx, L->Bpack);
+  i8ie_free(ctx, L->Bpack2);
   i8ie_free(ctx, L->wsum);
   i8ie_free(ctx, L->oc);
+  i8ie_free(ctx, L->ocp);
+  i8ie_free(ctx, L->biasf);
   delete L;
   return I8IE_OK;
 }

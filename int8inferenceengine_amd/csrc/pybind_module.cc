@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <iostream>
 #include <memory>
 #include <random>
@@ -77,6 +78,19 @@ struct Storage {
   void* dev = nullptr;
   std::vector<unsigned char> host;
   bool host_valid = false;
+  // physical layout of a 4-D u8 activation: the engine keeps NHWC between layers and
+  // converts back to the reference's NCHW only when the bytes are observed
+  int layout = I8IE_LAYOUT_NCHW;
+  int dn = 0, dc = 0, dh = 0, dw = 0;  // logical NCHW dims, valid when layout == NHWC
+  void to_nchw() {
+    if (layout == I8IE_LAYOUT_NCHW) return;
+    void* fresh = nullptr;
+    check(i8ie_malloc(ctx(), bytes, &fresh));
+    check(i8ie_layout_convert_u8(ctx(), (const uint8_t*)dev, (uint8_t*)fresh, dn, dc, dh, dw, 0));
+    i8ie_free(ctx(), dev);  // stream-ordered: the conversion above still reads it, reuse is queued behind
+    dev = fresh;
+    layout = I8IE_LAYOUT_NCHW;
+  }
   ~Storage() {
     if (dev && rt().ctx) i8ie_free(rt().ctx, dev);
   }
@@ -119,6 +133,16 @@ struct Tensor {
   ssize_t size = 0;
   float scale = 1;      // include/tensor.h:153
   u8_t zero_point = 0;  // include/tensor.h:154
+  // A layer forward that has been recorded but not launched yet: lets a following relu
+  // fold into the epilogue.  Launching is observationally identical to the eager call.
+  std::shared_ptr<std::function<std::shared_ptr<Storage>(bool)>> pend;
+  bool pend_relu = false;
+
+  void realize() {
+    if (!pend) return;
+    st = (*pend)(pend_relu);
+    pend.reset();
+  }
 
   Tensor() = default;
   explicit Tensor(std::vector<ssize_t> shp) : shape(std::move(shp)) {
@@ -126,17 +150,30 @@ struct Tensor {
     for (ssize_t d : shape) size *= d;
     st = device_storage((size_t)size * sizeof(T));
   }
-  T* dptr() const {
+  T* dptr() {  // NCHW / row-major bytes, as the reference lays them out
+    realize();
+    if (!st) throw std::runtime_error("i8ie: empty tensor");
+    st->to_nchw();
+    return static_cast<T*>(st->device_ptr());
+  }
+  T* dptr_any() {  // whatever layout the storage is in (see st->layout)
+    realize();
     if (!st) throw std::runtime_error("i8ie: empty tensor");
     return static_cast<T*>(st->device_ptr());
   }
-  py::array_t<T> numpy() const {
+  py::array_t<T> numpy() {
+    realize();
     py::array_t<T> out(shape);
-    if (st && size > 0) st->read_back(out.mutable_data());
+    if (st && size > 0) {
+      st->to_nchw();
+      st->read_back(out.mutable_data());
+    }
     return out;
   }
   // include/tensor.h:106-133: at most one -1, no zeros, sizes must match
-  Tensor<T> reshape(std::vector<ssize_t> shp) const {
+  Tensor<T> reshape(std::vector<ssize_t> shp) {
+    realize();
+    if (st) st->to_nchw();  // views are defined on the reference's element order
     ssize_t midx = -1, sz = 1;
     for (size_t i = 0; i < shp.size(); ++i) {
       if (shp[i] < 0) {
@@ -184,15 +221,20 @@ void bind_tensor(py::module_& m, const char* name) {
       .def("zero_point", [](const Tensor<T>& t) { return t.zero_point; })
       .def("scale", [](const Tensor<T>& t) { return t.scale; })
       .def("sum",
-           [](const Tensor<T>& t) {  // src/pybind11.cc:18-25: sequential fp32 sum
+           [](Tensor<T>& t) {  // src/pybind11.cc:18-25: sequential fp32 sum
              py::array_t<T> a = t.numpy();
              const T* p = a.data();
              float s = 0;
              for (ssize_t i = 0; i < t.size; ++i) s += p[i];
              return s;
            })
-      .def("ref_count", [](const Tensor<T>& t) { return t.st ? (long)t.st.use_count() : 0L; })
-      .def("reshape", [](const Tensor<T>& t, std::vector<ssize_t> shape) { return t.reshape(std::move(shape)); })
+      .def("ref_count",
+           [](Tensor<T>& t) {
+             t.realize();
+             return t.st ? (long)t.st.use_count() : 0L;
+           })
+      .def("reshape", [](Tensor<T>& t, std::vector<ssize_t> shape) { return t.reshape(std::move(shape)); })
+      .def("layout", [](Tensor<T>& t) { t.realize(); return t.st ? t.st->layout : 0; })
       .def("prefetch", [](Tensor<T>& t) { (void)t.dptr(); })
       .def("nbytes", [](const Tensor<T>& t) { return (size_t)t.size * sizeof(T); });
 }
@@ -211,10 +253,25 @@ Tensor<float> dequantize(Tensor<u8_t>& in) {  // src/quantize_utils.cc:54-58
   return out;
 }
 Tensor<u8_t> relu_u8(Tensor<u8_t>& in) {  // src/functional.cc:15-26
+  if (in.pend && !in.pend_relu) {
+    // `in` is a layer output that has not been launched: record layer+relu as one launch.
+    // `in` itself stays pending (if it is ever observed it launches without the relu).
+    Tensor<u8_t> out;
+    out.shape = in.shape;
+    out.size = in.size;
+    out.scale = in.scale;
+    out.zero_point = in.zero_point;
+    out.pend = in.pend;
+    out.pend_relu = true;
+    return out;
+  }
+  const uint8_t* src = in.dptr_any();
   Tensor<u8_t> out(in.shape);
   out.scale = in.scale;
   out.zero_point = in.zero_point;
-  check(i8ie_relu_u8(ctx(), in.dptr(), out.dptr(), in.size, in.zero_point));
+  out.st->layout = in.st->layout;  // elementwise: layout carries over
+  out.st->dn = in.st->dn; out.st->dc = in.st->dc; out.st->dh = in.st->dh; out.st->dw = in.st->dw;
+  check(i8ie_relu_u8(ctx(), src, out.dptr_any(), in.size, in.zero_point));
   return out;
 }
 Tensor<float> relu_f32(Tensor<float>& in) {  // src/functional.cc:5-13
@@ -233,6 +290,15 @@ Tensor<u8_t> max_pool2d_u8(Tensor<u8_t>& in, ssize_t k, ssize_t s) {  // src/fun
   Tensor<u8_t> out(pool_shape(in, k, s));
   out.scale = in.scale;
   out.zero_point = in.zero_point;
+  const uint8_t* src = in.dptr_any();
+  if (in.st->layout == I8IE_LAYOUT_NHWC && in.shape[1] % 16 == 0) {
+    check(i8ie_maxpool2d_u8_nhwc(ctx(), src, out.dptr_any(), (int)in.shape[0], (int)in.shape[1], (int)in.shape[2],
+                                 (int)in.shape[3], (int)k, (int)s));
+    out.st->layout = I8IE_LAYOUT_NHWC;
+    out.st->dn = (int)out.shape[0]; out.st->dc = (int)out.shape[1]; out.st->dh = (int)out.shape[2];
+    out.st->dw = (int)out.shape[3];
+    return out;
+  }
   check(i8ie_maxpool2d_u8(ctx(), in.dptr(), out.dptr(), (int)in.shape[0], (int)in.shape[1], (int)in.shape[2],
                           (int)in.shape[3], (int)k, (int)s));
   return out;
@@ -297,10 +363,7 @@ class BaseLayer {
     load_weight(w);
     load_bias(b);
   }
-  virtual ~BaseLayer() {
-    release_fp32_dev();
-    if (q_) i8ie_layer_destroy(q_);
-  }
+  virtual ~BaseLayer() { release_fp32_dev(); }
   BaseLayer(const BaseLayer&) = delete;
   BaseLayer& operator=(const BaseLayer&) = delete;
 
@@ -347,8 +410,9 @@ class BaseLayer {
     check(i8ie_quantize_weight(w_.data(), (int64_t)w_.size(), b_.data(), (int64_t)b_.size(),
                                reinterpret_cast<int8_t*>(qw_.data()), reinterpret_cast<int8_t*>(qb_.data()),
                                &w_scale_));
-    make_handle(n);
-    check(i8ie_layer_set_output_qparams(q_, scale_, zero_point_));
+    i8ie_layer* raw = make_handle(n);
+    q_ = std::shared_ptr<i8ie_layer>(raw, [](i8ie_layer* l) { i8ie_layer_destroy(l); });
+    check(i8ie_layer_set_output_qparams(q_.get(), scale_, zero_point_));
     is_preparing_ = false;
     is_quantized_ = true;
     std::vector<float>().swap(w_);  // src/layer.cc:52-53: FP32 weights are released
@@ -361,7 +425,7 @@ class BaseLayer {
     scale_ = s;
     zero_point_ = (u8_t)zp;
     qparams_overridden_ = true;
-    if (q_) check(i8ie_layer_set_output_qparams(q_, scale_, zero_point_));
+    if (q_) check(i8ie_layer_set_output_qparams(q_.get(), scale_, zero_point_));
   }
   std::tuple<float, int> output_qparams() const { return std::make_tuple(scale_, (int)zero_point_); }
   py::array_t<s8_t> q_weight() const {
@@ -384,7 +448,39 @@ class BaseLayer {
 
  protected:
   virtual void check_shapes() const = 0;
-  virtual void make_handle(ssize_t n) = 0;
+  virtual i8ie_layer* make_handle(ssize_t n) = 0;
+  // Deferred INT8 forward: returns a tensor whose launch happens when it is first needed.
+  Tensor<u8_t> defer(Tensor<u8_t>& in, std::vector<ssize_t> oshape, int m, int h, int w, bool spatial) {
+    Tensor<u8_t> out;
+    out.shape = std::move(oshape);
+    out.size = 1;
+    for (ssize_t d : out.shape) out.size *= d;
+    out.scale = scale_;
+    out.zero_point = zero_point_;
+    std::shared_ptr<i8ie_layer> handle = q_;
+    Tensor<u8_t> src = in;  // shares the input's storage / pending launch
+    const float s_in = in.scale;
+    const u8_t zp_in = in.zero_point;
+    const std::vector<ssize_t> oshp = out.shape;
+    const size_t obytes = (size_t)out.size;
+    out.pend = std::make_shared<std::function<std::shared_ptr<Storage>(bool)>>(
+        [handle, src, s_in, zp_in, m, h, w, spatial, oshp, obytes](bool relu) mutable {
+          const uint8_t* ip = spatial ? src.dptr_any() : src.dptr();
+          const int in_layout = src.st->layout;
+          int out_layout = I8IE_LAYOUT_NCHW;
+          if (spatial) check(i8ie_layer_preferred_layout(handle.get(), &out_layout));
+          auto st = device_storage(obytes);
+          check(i8ie_layer_forward_fused(handle.get(), ip, in_layout, m, h, w, s_in, zp_in, relu ? 1 : 0,
+                                         (uint8_t*)st->dev, out_layout, nullptr));
+          if (out_layout == I8IE_LAYOUT_NHWC) {
+            st->layout = I8IE_LAYOUT_NHWC;
+            st->dn = (int)oshp[0]; st->dc = (int)oshp[1]; st->dh = (int)oshp[2]; st->dw = (int)oshp[3];
+          }
+          src = Tensor<u8_t>();  // release the input as soon as the launch is queued
+          return st;
+        });
+    return out;
+  }
   void need_quantized() const {
     if (!is_quantized_) throw std::runtime_error("i8ie: layer is not converted (call convert() first)");
   }
@@ -406,7 +502,7 @@ class BaseLayer {
     }
     w_dev_ = b_dev_ = nullptr;
   }
-  void maybe_sample(const Tensor<float>& out) {  // src/conv2d.cc:94-96, src/fully_connected.cc:17-19
+  void maybe_sample(Tensor<float>& out) {  // src/conv2d.cc:94-96, src/fully_connected.cc:17-19
     if (!is_preparing_) return;
     py::array_t<float> a = out.numpy();
     cal_->sample(a.data(), out.size);
@@ -425,7 +521,7 @@ class BaseLayer {
   bool qparams_overridden_ = false;
   float scale_ = 1;       // include/layer.h:46
   u8_t zero_point_ = 0;   // include/layer.h:47
-  i8ie_layer* q_ = nullptr;
+  std::shared_ptr<i8ie_layer> q_;
 };
 
 class Linear : public BaseLayer {
@@ -452,17 +548,13 @@ class Linear : public BaseLayer {
     if (in.shape.empty() || in.shape.back() != k)
       throw std::runtime_error("i8ie: Linear: input's last dimension must equal in_features");
     const ssize_t m = in.size / k;
+    if (!want_acc) return std::make_tuple(defer(in, {m, n}, (int)m, 0, 0, false), py::object(py::none()));
     Tensor<u8_t> out({m, n});
     out.scale = scale_;
     out.zero_point = zero_point_;
-    py::object acc_np = py::none();
-    if (want_acc) {
-      Tensor<int32_t> acc({m, n});
-      check(i8ie_layer_forward(q_, in.dptr(), (int)m, 0, 0, in.scale, in.zero_point, out.dptr(), acc.dptr()));
-      acc_np = acc.numpy();
-    } else {
-      check(i8ie_layer_forward(q_, in.dptr(), (int)m, 0, 0, in.scale, in.zero_point, out.dptr(), nullptr));
-    }
+    Tensor<int32_t> acc({m, n});
+    check(i8ie_layer_forward(q_.get(), in.dptr(), (int)m, 0, 0, in.scale, in.zero_point, out.dptr(), acc.dptr()));
+    py::object acc_np = acc.numpy();
     return std::make_tuple(std::move(out), acc_np);
   }
 
@@ -471,9 +563,11 @@ class Linear : public BaseLayer {
     if (wshape_.size() != 2) throw std::runtime_error("i8ie: Linear weight must be [out_features, in_features]");
     if (has_fp32_ && (ssize_t)b_.size() != wshape_[0]) throw std::runtime_error("i8ie: Linear bias size mismatch");
   }
-  void make_handle(ssize_t n) override {
+  i8ie_layer* make_handle(ssize_t n) override {
+    i8ie_layer* l = nullptr;
     check(i8ie_linear_create(ctx(), reinterpret_cast<const int8_t*>(qw_.data()),
-                             reinterpret_cast<const int8_t*>(qb_.data()), (int)n, (int)wshape_[1], w_scale_, &q_));
+                             reinterpret_cast<const int8_t*>(qb_.data()), (int)n, (int)wshape_[1], w_scale_, &l));
+    return l;
   }
 };
 
@@ -512,18 +606,15 @@ class Conv2d : public BaseLayer {
   }
   std::tuple<Tensor<u8_t>, py::object> forward_u8(Tensor<u8_t>& in, bool want_acc) {  // src/conv2d.cc:100-142
     need_quantized();
-    Tensor<u8_t> out(out_shape(in.shape));
+    std::vector<ssize_t> oshape = out_shape(in.shape);
+    const int n = (int)in.shape[0], h = (int)in.shape[2], w = (int)in.shape[3];
+    if (!want_acc) return std::make_tuple(defer(in, oshape, n, h, w, true), py::object(py::none()));
+    Tensor<u8_t> out(oshape);
     out.scale = scale_;
     out.zero_point = zero_point_;
-    py::object acc_np = py::none();
-    const int n = (int)in.shape[0], h = (int)in.shape[2], w = (int)in.shape[3];
-    if (want_acc) {
-      Tensor<int32_t> acc({out.shape[0], out.shape[2] * out.shape[3], out.shape[1]});
-      check(i8ie_layer_forward(q_, in.dptr(), n, h, w, in.scale, in.zero_point, out.dptr(), acc.dptr()));
-      acc_np = acc.numpy();
-    } else {
-      check(i8ie_layer_forward(q_, in.dptr(), n, h, w, in.scale, in.zero_point, out.dptr(), nullptr));
-    }
+    Tensor<int32_t> acc({out.shape[0], out.shape[2] * out.shape[3], out.shape[1]});
+    check(i8ie_layer_forward(q_.get(), in.dptr(), n, h, w, in.scale, in.zero_point, out.dptr(), acc.dptr()));
+    py::object acc_np = acc.numpy();
     return std::make_tuple(std::move(out), acc_np);
   }
 
@@ -532,10 +623,12 @@ class Conv2d : public BaseLayer {
     if (wshape_.size() != 4) throw std::runtime_error("i8ie: Conv2d weight must be [out, in, kh, kw]");
     if (has_fp32_ && (ssize_t)b_.size() != wshape_[0]) throw std::runtime_error("i8ie: Conv2d bias size mismatch");
   }
-  void make_handle(ssize_t n) override {
+  i8ie_layer* make_handle(ssize_t n) override {
+    i8ie_layer* l = nullptr;
     check(i8ie_conv2d_create(ctx(), reinterpret_cast<const int8_t*>(qw_.data()),
                              reinterpret_cast<const int8_t*>(qb_.data()), (int)n, (int)wshape_[1], (int)wshape_[2],
-                             (int)wshape_[3], (int)stride_, (int)padding_, w_scale_, &q_));
+                             (int)wshape_[3], (int)stride_, (int)padding_, w_scale_, &l));
+    return l;
   }
 
  private:
@@ -623,6 +716,7 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
     return py::make_tuple(live, cached, allocs);
   });
   m.def("trim", []() { check(i8ie_trim(ctx())); });
+  m.def("force_fallback", [](bool on) { check(i8ie_ctx_set_option(ctx(), I8IE_OPT_FORCE_FALLBACK, on ? 1 : 0)); });
   m.def("profile_start", []() { check(i8ie_profile_start(ctx())); });
   m.def("profile_stop", []() {
     std::vector<i8ie_profile_entry> e(64);

@@ -208,3 +208,113 @@ def test_conv_batch_invariance_at_bench_size(gpu, orc):
     mid, _ = gpu.layer_forward("conv", big[500:507], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
                                cs["s_out"], cs["zp_out"], stride=1, pad=1, want_acc=False)
     assert np.array_equal(out[500:507], mid)
+
+
+# ================================================================= v2 paths =====
+# i8ie_layer_forward_fused: implicit-GEMM conv over NHWC (path A), grouped small-C first
+# layer (path B), im2col fallback (path F), fused relu, all layout combinations.
+FUSED_GEOMS = [
+    (2, 3, 224, 224, 96, 11, 4, 2),   # AlexNet conv1 -> path B
+    (2, 96, 27, 27, 256, 5, 1, 2),    # conv2 -> path A
+    (3, 256, 13, 13, 384, 3, 1, 1),   # conv3
+    (2, 384, 13, 13, 256, 3, 1, 1),   # conv5
+    (3, 16, 9, 11, 24, 3, 2, 1),      # path A, ragged N (24 % 16 != 0), stride 2, non-square
+    (2, 32, 8, 8, 40, 1, 1, 0),       # 1x1
+    (2, 48, 7, 7, 16, 7, 1, 3),       # kernel = image, big padding
+    (2, 4, 23, 29, 20, 7, 4, 3),      # path B with c = 4, non-square
+    (2, 1, 28, 28, 20, 5, 4, 0),      # path B with c = 1
+    (2, 10, 22, 22, 20, 3, 1, 1),     # path F (c % 16 != 0, stride 1)
+]
+
+
+@pytest.mark.parametrize("geom", FUSED_GEOMS)
+@pytest.mark.parametrize("layouts", [(False, False), (True, True), (False, True), (True, False)])
+def test_conv_fused_all_layouts(gpu, orc, geom, layouts):
+    n, c, h, w, kc, k, stride, pad = geom
+    in_nhwc, out_nhwc = layouts
+    cs = synth.conv_case(orc, 31 + sum(geom), n, c, h, w, kc, k, stride, pad)
+    for relu in (False, True):
+        out, acc, _ = gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"],
+                                              cs["s_w"], cs["s_out"], cs["zp_out"], stride=stride, pad=pad,
+                                              in_nhwc=in_nhwc, out_nhwc=out_nhwc, relu=relu)
+        want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
+        assert np.array_equal(acc, cs["acc"])
+        assert np.array_equal(out, want)
+
+
+def test_preferred_layout_and_forced_fallback(gpu, orc):
+    cs = synth.conv_case(orc, 41, 2, 96, 27, 27, 256, 5, 1, 2)
+    try:
+        for force in (False, True):
+            gpu.set_force_fallback(force)
+            out, acc, pref = gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"],
+                                                     cs["s_w"], cs["s_out"], cs["zp_out"], stride=1, pad=2, relu=True,
+                                                     out_nhwc=True)
+            assert pref == (0 if force else 1)
+            assert np.array_equal(acc, cs["acc"]) and np.array_equal(out, orc.relu(cs["out"], cs["zp_out"]))
+    finally:
+        gpu.set_force_fallback(False)
+
+
+@pytest.mark.parametrize("mkn", [(33, 64, 40), (100, 784, 10), (5, 500, 10), (130, 4096, 300), (64, 9216, 256)])
+def test_linear_fused_relu(gpu, orc, mkn):
+    m, k, n = mkn
+    c = synth.linear_case(orc, 200 + m + k + n, m, k, n)
+    for relu in (False, True):
+        out, acc, _ = gpu.layer_forward_fused("linear", c["q_in"], c["qw"], c["qb"], c["s_in"], c["zp_in"], c["s_w"],
+                                              c["s_out"], c["zp_out"], relu=relu)
+        want = orc.relu(c["out"], c["zp_out"]) if relu else c["out"]
+        assert np.array_equal(acc, c["acc"]) and np.array_equal(out, want)
+
+
+def test_requant_fast_path_boundaries(gpu, orc):
+    """Scales that put the real-valued result exactly on / next to integer boundaries, both clamps,
+    huge and tiny ratios: the fast requantiser must agree with the exact sequence everywhere."""
+    rng = np.random.default_rng(17)
+    m, k, n = 96, 128, 128
+    q_in = rng.integers(0, 256, (m, k), dtype=np.uint8)
+    qw = rng.integers(-3, 4, (n, k)).astype(np.int8)
+    qw[:16] = 0
+    qw[np.arange(16), np.arange(16)] = 1  # first 16 features: accumulator = one input byte (+offsets)
+    qb = rng.integers(-20, 20, n).astype(np.int8)
+    combos = [(1.0, 1.0, 1.0, 0), (1.0, 1.0, 1.0, 100), (0.5, 1.0, 0.25, 128), (1.0, 0.5, 4.0, 7),
+              (0.025, 0.0031, 0.11, 0), (0.1, 0.1, 0.01, 255), (3.0, 7.0, 0.001, 3), (1e-3, 1e-3, 10.0, 200),
+              (0.3333333, 0.1428571, 0.0476190, 64), (1.0, 1.0, 3.0, 1), (2.0, 1.0, 1.0, 254), (1.0, 1.0, 256.0, 0)]
+    combos += [(float(a), float(b), float(c), int(z)) for a, b, c, z in
+               zip(rng.uniform(0.001, 0.2, 12), rng.uniform(0.0005, 0.01, 12), rng.uniform(0.005, 0.5, 12),
+                   rng.integers(0, 256, 12))]
+    for s_in, s_w, s_out, zp_out in combos:
+        for zp_in in (0, 131):
+            want, pre, _ = orc.linear(q_in, qw, qb, np.float32(s_in), zp_in, np.float32(s_w), np.float32(s_out),
+                                      zp_out, want_acc=True)
+            out, acc, _ = gpu.layer_forward_fused("linear", q_in, qw, qb, np.float32(s_in), zp_in, np.float32(s_w),
+                                                  np.float32(s_out), zp_out)
+            assert np.array_equal(acc, pre)
+            assert np.array_equal(out, want), (s_in, s_w, s_out, zp_out, zp_in)
+
+
+def test_layout_convert_and_nhwc_pool(gpu, orc):
+    rng = np.random.default_rng(23)
+    for shape in [(2, 96, 55, 55), (3, 256, 13, 13), (1, 16, 5, 7), (2, 3, 9, 9), (5, 130, 3, 2)]:
+        q = rng.integers(0, 256, shape, dtype=np.uint8)
+        nhwc = gpu.layout_convert(q, True)
+        assert np.array_equal(nhwc, q.transpose(0, 2, 3, 1))
+        assert np.array_equal(gpu.layout_convert(nhwc, False), q)
+    for shape, k, s in [((2, 96, 55, 55), 3, 2), ((2, 256, 27, 27), 3, 2), ((3, 256, 13, 13), 3, 2),
+                        ((2, 32, 8, 8), 2, 2), ((1, 16, 4, 4), 2, 1), ((1, 16, 4, 4), 1, 2), ((2, 48, 7, 9), 3, 3)]:
+        q = rng.integers(0, 256, shape, dtype=np.uint8)
+        got = gpu.max_pool2d_nhwc(np.ascontiguousarray(q.transpose(0, 2, 3, 1)), k, s)
+        assert np.array_equal(got.transpose(0, 3, 1, 2), orc.max_pool2d(q, k, s))
+
+
+def test_conv_batch_invariance_fused_at_bench_size(gpu, orc):
+    n = 1000
+    cs = synth.conv_case(orc, 21, 4, 256, 13, 13, 384, 3, 1, 1)
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 256, (n, 256, 13, 13), dtype=np.uint8)
+    big[:4] = cs["q_in"]
+    big[-4:] = cs["q_in"]
+    out, _, _ = gpu.layer_forward_fused("conv", big, cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
+                                        cs["s_out"], cs["zp_out"], stride=1, pad=1, in_nhwc=True, out_nhwc=True,
+                                        want_acc=False)
+    assert np.array_equal(out[:4], cs["out"]) and np.array_equal(out[-4:], cs["out"])
