@@ -159,7 +159,12 @@ def main():
     value = n_total * args.steps / elapsed
 
     # ---- roofline of the dominant kernel (by device time) --------------------------------------
-    kernels = {k: {"launches": int(v[0]), "ms": v[1], "ops": v[2], "bytes": v[3]} for k, v in prof.items()}
+    per_shape = {k: {"launches": int(v[0]), "ms": v[1], "ops": v[2], "bytes": v[3]} for k, v in prof.items()}
+    kernels = {}
+    for k, v in per_shape.items():  # entries are "kernel|shape": group by kernel for the roofline
+        e = kernels.setdefault(k.split("|")[0], {"launches": 0, "ms": 0.0, "ops": 0.0, "bytes": 0.0})
+        for f in e:
+            e[f] += v[f]
     mfma = {k: v for k, v in kernels.items() if v["ops"] > 0}
     dom = max(mfma, key=lambda k: mfma[k]["ms"])
     d = mfma[dom]
@@ -172,6 +177,10 @@ def main():
     }
     total_dev_ms = sum(v["ms"] for v in kernels.values())
     breakdown = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
+    per_layer = {k: {"ms": round(v["ms"] / args.steps, 4),
+                     "tops": round(v["ops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ops"] else None,
+                     "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                 for k, v in sorted(per_shape.items(), key=lambda kv: -kv[1]["ms"])}
     macs = wl.macs_per_image(name)
     whole = {"int8_tops_whole_step": round(value * macs * 2 / 1e12, 2),
              "frac_of_int8_peak_whole_step": round(value * macs * 2 / 1e12 / INT8_DENSE_PEAK_TOPS, 4),
@@ -216,7 +225,7 @@ def main():
                    % ((name,) + wl.NETWORKS[name][2] + (n_total, world)),
                    "global_batch": n_total, "per_gpu_batch": stop - start, "parallelism": "batch-shard x%d + logits all-gather" % world},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "whole_step": whole,
-        "kernel_ms_per_step": breakdown, "top1_vs_fp32_teacher": round(state["correct"] / n_total, 4),
+        "kernel_ms_per_step": breakdown, "per_launch_shape": per_layer, "top1_vs_fp32_teacher": round(state["correct"] / n_total, 4),
         "h2d_ms_fp32_input": round(h2d_ms, 2),
         "value_with_h2d": round(n_total / ((ms_per_step + h2d_ms) * 1e-3), 1),
     }

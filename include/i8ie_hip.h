@@ -178,20 +178,30 @@ int i8ie_layer_forward(i8ie_layer* layer, const uint8_t* in_dev, int m, int h, i
                        uint8_t zp_in, uint8_t* out_dev, int32_t* acc_dbg_dev);
 /* Same computation with the layout conversions and the following relu<u8>
  * (src/functional.cc:15-26: out = max(out, zp_out)) folded in.  in/out may each be NCHW or
- * NHWC; i8ie_layer_preferred_layout tells which output layout avoids a conversion. */
-int i8ie_layer_forward_fused(i8ie_layer* layer, const uint8_t* in_dev, int in_layout, int m, int h, int w,
-                             float s_in, uint8_t zp_in, int relu, uint8_t* out_dev, int out_layout,
-                             int32_t* acc_dbg_dev);
+ * NHWC; an NHWC tensor may carry a physical border of `border` pixels on each side of H and W
+ * ([n][h+2b][w+2b][c]) whose bytes hold the tensor's zero point: a conv whose input border
+ * covers its padding gathers with no bounds checks (the pad-with-zero-point rule of
+ * src/conv2d.cc:24-28 is materialised by the producer).  When out_border > 0 this call fills
+ * the border of `out` with zp_out.  i8ie_layer_preferred_layout tells which output layout
+ * avoids a conversion. */
+int i8ie_layer_forward_fused(i8ie_layer* layer, const uint8_t* in_dev, int in_layout, int in_border, int m,
+                             int h, int w, float s_in, uint8_t zp_in, int relu, uint8_t* out_dev,
+                             int out_layout, int out_border, int32_t* acc_dbg_dev);
 int i8ie_layer_preferred_layout(const i8ie_layer* layer, int* layout);
+/* padding of a conv layer (0 for Linear): the input border that makes its gather predicate-free */
+int i8ie_layer_padding(const i8ie_layer* layer, int* pad);
 int i8ie_layer_destroy(i8ie_layer* layer);
 
 /* ---- NHWC companions of the elementwise ops (internal layout between layers) ------------ */
-/* NCHW <-> NHWC of a u8 tensor [n,c,h,w] (to_nhwc != 0: NCHW -> NHWC) */
+/* NCHW [n,c,h,w] <-> NHWC [n,h+2b,w+2b,c] of a u8 tensor (to_nhwc != 0: NCHW -> NHWC, the border
+ * of the destination is filled with border_value) */
 int i8ie_layout_convert_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int n, int c, int h,
-                           int w, int to_nhwc);
-/* max_pool2d<u8_t> (src/functional.cc:36-64) on NHWC data, channels % 16 == 0 */
-int i8ie_maxpool2d_u8_nhwc(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int n, int c, int h,
-                           int w, int kernel_size, int stride);
+                           int w, int to_nhwc, int border, uint8_t border_value);
+/* max_pool2d<u8_t> (src/functional.cc:36-64) on NHWC data, channels % 16 == 0; h, w are the
+ * logical input dims; the output border (if any) is filled with border_value */
+int i8ie_maxpool2d_u8_nhwc(i8ie_ctx* ctx, const uint8_t* in_dev, int in_border, uint8_t* out_dev,
+                           int out_border, int n, int c, int h, int w, int kernel_size, int stride,
+                           uint8_t border_value);
 
 #ifdef __cplusplus
 }

@@ -1,24 +1,31 @@
-// i8ie_igemm.hip -- second-generation contraction kernel: implicit-GEMM Conv2d
-// over NHWC u8 activations (no materialised im2col) and the same core for Linear.
+// i8ie_igemm.hip -- implicit-GEMM Conv2d over NHWC u8 activations (no materialised
+// im2col) and the same MFMA core for Linear.
 //
 //   C[r][j] = sum_k A_u8[r][k] * W_s8[j][k] + oc[j]        exact int32, = the
 //   cblas_gemm_s8u8s32 result of src/conv2d.cc:131-133 / src/fully_connected.cc:39-41
 //   (K is walked in (kh, kw, c) order instead of (c, kh, kw); integer sums commute)
 //
-// Differences from the v1 kernel (i8ie_gemm.hip, kept as the any-geometry fallback):
-//   * A operand is gathered straight from the NHWC activation tensor: a row of the
-//     virtual im2col matrix is an output pixel, a 16-byte K chunk is 16 consecutive
-//     channels of one (kh, kw) tap; out-of-bounds taps are filled with the input
-//     zero point (src/conv2d.cc:24-28).  Removes the im2col write+read entirely.
-//   * BK = 128 bytes: 8 lanes cover one 128-byte line of a row, so global loads are
-//     whole cache lines (MI355X guide: fragment-shaped 64-B pieces cost TA cycles).
-//   * MFMA operands are swapped (weights as the row operand): the accumulator then
-//     has the activation row on the lane and 4 consecutive output features in 4
-//     consecutive registers, so the row-major (= NHWC) epilogue packs 4 u8 per lane.
-//   * The requantiser has a fast path that is provably identical to the reference's
-//     ((float)C*s_in)*s_w/s_out + zp sequence and falls back to that exact sequence
-//     whenever the fused estimate is within 2^-11 of an integer boundary.
-//   * Optional fused ReLU (clamp-low at zp_out; relu<u8> of src/functional.cc:15-26).
+// Structure (gfx950):
+//   * A operand gathered straight from the NHWC activation tensor, which is PHYSICALLY
+//     padded with the input zero point (src/conv2d.cc:24-28) by its producer, so the
+//     gather has no bounds predicates: one 32-bit offset add + buffer_load_dwordx4 per
+//     16-byte K chunk (16 channels of one tap).  Rows past M and the K tail read
+//     whatever is there (or 0 past the end of the buffer): their B columns are zero /
+//     their outputs are never stored.
+//   * BK = 128 bytes per stage, 8 lanes per 128-byte line; two LDS stages, ONE barrier
+//     per K tile; LDS rows padded to 144 B: ds_read_b128 fragment reads are
+//     conflict-free (144/16 = 9 is odd) and the k-step offset is an immediate.
+//   * u8 -> s8 re-bias (x ^ 0x80) on the way into LDS; 128 * sum_k W joins oc[j] in the
+//     accumulator's initial value, so the accumulator is the reference's C bit for bit.
+//   * MFMA operands swapped (weights are the row operand): the lane holds one
+//     activation row and 4 consecutive registers hold 4 consecutive output features,
+//     so the row-major (= NHWC) epilogue packs 4 u8 per lane.
+//   * Requantiser fast path, provably identical to ((float)C*s_in)*s_w/s_out + zp with
+//     an exact-sequence fallback near rounding boundaries; optional fused ReLU
+//     (src/functional.cc:15-26); optional physically padded output.
+#include <cstdio>
+#include <type_traits>
+
 #include "i8ie_internal.h"
 
 namespace {
@@ -26,85 +33,80 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int BK2 = 128;  // bytes of K per LDS tile: 8 chunks of 16 B, 4 MFMA k-steps
-
-// 16-B chunk `c` (0..7) of tile row `row`; XOR with (row>>1)&7 makes every 16-lane
-// ds_read_b128 group (rows distinct mod 16, same c) hit 16 distinct 4-bank slots.
-__device__ __forceinline__ int lds_off2(int row, int c) { return row * BK2 + ((c ^ ((row >> 1) & 7)) << 4); }
+constexpr int BK2 = 128;   // bytes of K per stage: 8 chunks of 16 B = 4 MFMA k-steps
+constexpr int LROW = 144;  // LDS row stride
 
 struct Requant {
   float sa, sb, sc, zpf, ms;
   int fast;
 };
 
-// src/quantize_utils.cc:30-33, exact sequence
-__device__ __forceinline__ int requant_exact(float cf, const Requant& q) {
-  float deq = (cf * q.sa) * q.sb;
-  float v = deq / q.sc + q.zpf;
-  return (v >= 255.0f) ? 255 : ((v < 0.0f) ? 0 : (int)v);
+// src/quantize_utils.cc:30-33, the exact sequence
+__device__ __forceinline__ int requant_exact(float cf, const Requant& q, int lo) {
+  const float deq = (cf * q.sa) * q.sb;
+  const float v = deq / q.sc + q.zpf;
+  const int u = (v >= 255.0f) ? 255 : ((v < 0.0f) ? 0 : (int)v);
+  return u > lo ? u : lo;
 }
 
-// Fast path.  est = fma(cf, ms, zp) with ms = fl(s_in*s_w/s_out) differs from the
-// reference's value by < 1.6e-4 whenever -1 < est < 256 (4 roundings of <= 2^-24
-// relative on magnitudes < 512), so if est is more than 2^-11
-// away from both neighbouring integers the reference value lies in the same unit
-// interval and trunc/clamp give clamp(floor(est), 0, 255).  est >= 256 / est <= -1
-// are the two clamps with the same margin.  Otherwise: the exact sequence.
-__device__ __forceinline__ int requant(int c, const Requant& q) {
+// est = fma(cf, ms, zp), ms = fl(s_in*s_w/s_out).  While -1 < est < 256 the reference value
+// v obeys |v - est| < 9.2e-5 (reference: 3 roundings on |C*s_in*s_w/s_out| < 256 and one on
+// |v| < 257; est: one rounding of ms and one of the fma), so when est is further than
+// 2^-12 from an integer, v lies in the same unit interval and trunc + clamp of v equals
+// clamp(floor(est), 0, 255).  est <= -1 / est >= 256 clamp with the same margin.  Anything
+// closer to an integer takes the exact sequence.  `lo` folds relu (max with zp_out) in.
+__device__ __forceinline__ int requant(int c, const Requant& q, int lo) {
   const float cf = (float)c;
   if (q.fast) {
     const float est = __builtin_fmaf(cf, q.ms, q.zpf);
     const float fl = __builtin_floorf(est);
     const float fr = est - fl;
-    const bool inside = (est > -1.0f) && (est < 256.0f);
-    const bool safe = !inside || ((fr > 4.8828125e-4f) && (fr < 1.0f - 4.8828125e-4f));
-    if (safe) {
-      int k = (int)fl;  // saturating conversion; est is finite here or far outside
-      k = est >= 256.0f ? 255 : (est <= -1.0f ? 0 : k);
-      return k < 0 ? 0 : (k > 255 ? 255 : k);
+    if (__builtin_fabsf(fr - 0.5f) <= 0.5f - 2.44140625e-4f) {
+      const int k = (int)fl;  // saturating; |est| beyond int range is far outside [0, 255] anyway
+      return k < lo ? lo : (k > 255 ? 255 : k);
     }
   }
-  return requant_exact(cf, q);
+  return requant_exact(cf, q, lo);
 }
 
 struct IgemmArgs {
   const uint8_t* A;
-  long lda;  // AMODE 0
+  unsigned a_bytes;  // readable bytes from A (buffer bound)
+  unsigned lda;      // AMODE 0: row pitch in bytes
   int M;
-  int Kchunks;  // valid 16-B chunks of K
-  // AMODE 1 (NHWC gather)
-  int H, W, C16;  // C16 = channels / 16
-  int KH, KW, sh, sw, ph, pw, OH, OW;
-  uint32_t zp_fill;  // input zero point replicated into 4 bytes
+  // AMODE 1: physically padded NHWC input [n][Hp][Wp][C]; A already points at the window
+  // origin of output pixel (0, 0)
+  unsigned img_pitch;  // Hp * Wp * C
+  unsigned row_pitch;  // Wp * C
+  unsigned C;          // channels (bytes per pixel), % 16 == 0
+  int sh, sw, OH, OW;
+  int RC;              // chunks per kernel row: KW * C / 16
+  unsigned row_jump;   // row_pitch - RC * 16
   // B
   const int8_t* B;  // [Npad][Kpad] zero padded, K order matches the A walk
+  unsigned b_bytes;
   int Kpad;
   int N;
-  const int32_t* ocp;   // [N] oc[j] + 128 * wsum[j]
-  const float* biasf;   // [N] (float)q_b[j] / s_in, Linear only (src/fully_connected.cc:44); else nullptr
+  const int32_t* ocp;  // [N] oc[j] + 128 * wsum[j]
+  const float* biasf;  // [N] (float)q_b[j] / s_in (Linear, src/fully_connected.cc:44)
   Requant rq;
-  int zp_out;
-  int relu;
-  int vec_store;  // N % 16 == 0 and out 16-byte aligned: 16-B row stores
-  uint8_t* out;  // [M][N]
-  int32_t* acc;  // nullptr or [M][N]: C before the Linear bias step / before requant
+  int relu_lo;  // zp_out when relu is fused, else 0
+  int vec_store;
+  uint8_t* out;  // [M][N], or bordered NHWC when ob > 0
+  int ob, OHp, OWp;
+  int32_t* acc;  // [M][N]
 };
 
-template <int AMODE, int WM, int WN, int TM, int TN>
+template <int AMODE, int WM, int WN, int TM, int TN, bool BIAS, bool ACC>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, int tiles_m, int tiles_n,
                                                                  int m_fastest) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
-  constexpr int A_PER = BM * 8 / NT;
-  constexpr int B_CH = BN * 8;
-  constexpr int B_PER = (B_CH + NT - 1) / NT;
-  static_assert(BM * 8 % NT == 0, "A staging map");
+  constexpr int A_PER = BM * 8 / NT, B_PER = BN * 8 / NT;
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "staging map");
+  constexpr int STAGE = (BM + BN) * LROW;
   constexpr int SROW = BN + 4;  // epilogue tile row stride: odd dword count -> conflict-free ds_write_b32
-  constexpr int MAIN_BYTES = (BM + BN) * BK2;
-  constexpr int EPI_BYTES = BM * SROW;
-  constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
-  uint8_t* smA = smem;
-  uint8_t* smB = smem + BM * BK2;
+  static_assert(BM * SROW <= 2 * STAGE, "epilogue tile fits");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -123,8 +125,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // ---- accumulators: D = W_tile x A_tile^T, row = feature, col = activation row ---
-  //   lane & 31 -> activation row; feature = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // ---- accumulators: D = W_tile x A_tile^T; lane & 31 -> activation row,
+  //      feature = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   v16i acc[TM][TN];
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
@@ -138,142 +140,147 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
     }
   }
 
-  // ---- A staging state: thread owns chunk column cA of rows (tid>>3) + 32*i ---------
+  // ---- staging state ------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.A), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.B), 0, p.b_bytes, 0x00020000);
   const int cA = tid & 7;
-  const uint8_t* a_ptr[A_PER];
-  int a_ih0[A_PER], a_iw0[A_PER];
+  unsigned a_off[A_PER], b_off[B_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     int gr = m0 + (tid >> 3) + (NT >> 3) * i;
-    gr = gr < p.M ? gr : p.M - 1;  // rows past M are computed and discarded
+    gr = gr < p.M ? gr : p.M - 1;  // rows past M: computed, never stored
     if (AMODE == 0) {
-      a_ptr[i] = p.A + (size_t)gr * p.lda;
-      a_ih0[i] = a_iw0[i] = 0;
+      a_off[i] = (unsigned)gr * p.lda;
     } else {
       const int P = p.OH * p.OW;
       const int img = gr / P, rem = gr - img * P;
       const int oh = rem / p.OW, ow = rem - oh * p.OW;
-      a_ih0[i] = oh * p.sh - p.ph;
-      a_iw0[i] = ow * p.sw - p.pw;
-      a_ptr[i] = p.A + (((long)img * p.H + a_ih0[i]) * p.W + a_iw0[i]) * ((long)p.C16 * 16);
+      a_off[i] = (unsigned)img * p.img_pitch + (unsigned)(oh * p.sh) * p.row_pitch + (unsigned)(ow * p.sw) * p.C;
     }
   }
-  // walk of this thread's K chunk q = cA, cA + 8, ... as (kh, kw, c16)
-  int q = cA, kh = 0, kw = 0, c16 = 0;
-  if (AMODE == 1) {
-    c16 = cA % p.C16;
-    const int tap = cA / p.C16;
-    kw = tap % p.KW;
-    kh = tap / p.KW;
-  }
-  const int8_t* b_ptr[B_PER];
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) {
     const int idx = tid + i * NT;
-    b_ptr[i] = p.B + (size_t)(n0 + (idx >> 3)) * p.Kpad + (idx & 7) * 16;
+    b_off[i] = (unsigned)(n0 + (idx >> 3)) * (unsigned)p.Kpad + (idx & 7) * 16;
+  }
+  // this thread's K chunk q = cA, cA + 8, ...: byte offset inside the window
+  unsigned koff;
+  int f = 0;
+  if (AMODE == 0) {
+    koff = cA * 16;
+  } else {
+    const int kh = cA / p.RC;
+    f = cA - kh * p.RC;
+    koff = (unsigned)kh * p.row_pitch + (unsigned)f * 16;
   }
 
   v4i ra[A_PER], rb[B_PER];
-  const v4i zfill = {(int)p.zp_fill, (int)p.zp_fill, (int)p.zp_fill, (int)p.zp_fill};
-
   auto load_tile = [&](int k0) {
-    const bool kvalid = q < p.Kchunks;
-    if (AMODE == 0) {
 #pragma unroll
-      for (int i = 0; i < A_PER; ++i)
-        ra[i] = kvalid ? *reinterpret_cast<const v4i*>(a_ptr[i] + (size_t)q * 16) : zfill;
-    } else {
-      const long koff = ((long)kh * p.W + kw) * ((long)p.C16 * 16) + c16 * 16;
-#pragma unroll
-      for (int i = 0; i < A_PER; ++i) {
-        const bool ok = kvalid && (unsigned)(a_ih0[i] + kh) < (unsigned)p.H && (unsigned)(a_iw0[i] + kw) < (unsigned)p.W;
-        ra[i] = ok ? *reinterpret_cast<const v4i*>(a_ptr[i] + koff) : zfill;
-      }
-    }
+    for (int i = 0; i < A_PER; ++i)
+      ra[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i] + koff, 0, 0));
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
-      if (B_CH % NT == 0 || tid + i * NT < B_CH) rb[i] = *reinterpret_cast<const v4i*>(b_ptr[i] + k0);
-    // advance the chunk walk by one K tile (8 chunks)
-    q += 8;
+      rb[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], k0, 0));
+    koff += BK2;
     if (AMODE == 1) {
-      c16 += 8;
-      while (c16 >= p.C16) {
-        c16 -= p.C16;
-        if (++kw == p.KW) {
-          kw = 0;
-          ++kh;
-        }
+      f += 8;
+      while (f >= p.RC) {  // next kernel row(s)
+        f -= p.RC;
+        koff += p.row_jump;
       }
     }
   };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      const v4i v = ra[i] ^ (int)0x80808080;  // u8 -> s8 re-bias (the +128*wsum term is in ocp)
-      *reinterpret_cast<v4i*>(smA + lds_off2((tid >> 3) + (NT >> 3) * i, cA)) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      const int idx = tid + i * NT;
-      if (B_CH % NT == 0 || idx < B_CH) *reinterpret_cast<v4i*>(smB + lds_off2(idx >> 3, idx & 7)) = rb[i];
-    }
-  };
 
-  const int nk = p.Kpad / BK2;
-  load_tile(0);
-  store_tile();
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile((kt + 1) * BK2);  // global loads in flight under the MFMAs
+  // LDS addresses (bytes from smem); stage s adds s * STAGE as an immediate
+  int a_wr[A_PER], b_wr[B_PER], a_rd[TM], b_rd[TN];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) a_wr[i] = ((tid >> 3) + (NT >> 3) * i) * LROW + cA * 16;
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int idx = tid + i * NT;
+    b_wr[i] = BM * LROW + (idx >> 3) * LROW + (idx & 7) * 16;
+  }
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) a_rd[mi] = ((wm * TM + mi) * 32 + (lane & 31)) * LROW + (lane >> 5) * 16;
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni)
+    b_rd[ni] = BM * LROW + ((wn * TN + ni) * 32 + (lane & 31)) * LROW + (lane >> 5) * 16;
+
+  auto store_tile = [&](auto sc) {
+    constexpr int S = decltype(sc)::value;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i)
+      *reinterpret_cast<v4i*>(smem + S * STAGE + a_wr[i]) = ra[i] ^ (int)0x80808080;  // u8 -> s8
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) *reinterpret_cast<v4i*>(smem + S * STAGE + b_wr[i]) = rb[i];
+  };
+  auto compute = [&](auto sc) {
+    constexpr int S = decltype(sc)::value;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int chunk = ks * 2 + (lane >> 5);
       v4i af[TM], bf[TN];
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
-        af[mi] = *reinterpret_cast<const v4i*>(smA + lds_off2((wm * TM + mi) * 32 + (lane & 31), chunk));
+        af[mi] = *reinterpret_cast<const v4i*>(smem + S * STAGE + ks * 32 + a_rd[mi]);
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni)
-        bf[ni] = *reinterpret_cast<const v4i*>(smB + lds_off2((wn * TN + ni) * 32 + (lane & 31), chunk));
+        bf[ni] = *reinterpret_cast<const v4i*>(smem + S * STAGE + ks * 32 + b_rd[ni]);
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
     }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  const int nk = p.Kpad / BK2;
+  load_tile(0);
+  store_tile(S0{});
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 1 < nk) load_tile((kt + 1) * BK2);  // global loads in flight under the MFMAs
+    compute(S0{});
+    if (kt + 1 < nk) store_tile(S1{});
     __syncthreads();
-    if (kt + 1 < nk) {
-      store_tile();
-      __syncthreads();
-    }
+    if (kt + 1 >= nk) break;
+    if (kt + 2 < nk) load_tile((kt + 2) * BK2);
+    compute(S1{});
+    if (kt + 2 < nk) store_tile(S0{});
+    __syncthreads();
   }
 
   // ---- epilogue: (bias) -> requant -> (relu) -> LDS tile [BM][BN] -> 16-B row stores ----
   const Requant rq = p.rq;
-  const int relu_lo = p.relu ? p.zp_out : 0;
+  const int lo = p.relu_lo;
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
-    const int lrow = (wm * TM + mi) * 32 + (lane & 31);
-    const int grow = m0 + lrow;
+  for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
+    for (int g = 0; g < 4; ++g) {
+      const int lcol0 = (wn * TN + ni) * 32 + 8 * g + 4 * (lane >> 5);
+      const int gcol0 = n0 + lcol0;
+      float bfv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (BIAS) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int lcol0 = (wn * TN + ni) * 32 + 8 * g + 4 * (lane >> 5);
-        const int gcol0 = n0 + lcol0;
+        for (int r = 0; r < 4; ++r) bfv[r] = gcol0 + r < p.N ? p.biasf[gcol0 + r] : 0.0f;
+      }
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int lrow = (wm * TM + mi) * 32 + (lane & 31);
         uint32_t packed = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int c = acc[mi][ni][g * 4 + r];
-          const int gcol = gcol0 + r;
-          if (p.acc != nullptr && grow < p.M && gcol < p.N) p.acc[(size_t)grow * p.N + gcol] = c;
-          if (p.biasf != nullptr) {
-            const float bfv = gcol < p.N ? p.biasf[gcol] : 0.0f;
-            c = (int)((float)c + bfv);  // src/fully_connected.cc:44: int += float
+          if (ACC) {
+            const int grow = m0 + lrow, gcol = gcol0 + r;
+            if (grow < p.M && gcol < p.N) p.acc[(size_t)grow * p.N + gcol] = c;
           }
-          int u = requant(c, rq);
-          u = u > relu_lo ? u : relu_lo;
-          packed |= (uint32_t)u << (8 * r);
+          if (BIAS) c = (int)((float)c + bfv[r]);  // src/fully_connected.cc:44: int += float
+          packed |= (uint32_t)requant(c, rq, lo) << (8 * r);
         }
         *reinterpret_cast<uint32_t*>(smem + lrow * SROW + lcol0) = packed;
       }
@@ -286,8 +293,15 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
       const int lrow = idx / CPR, ch = idx - lrow * CPR;
       const int grow = m0 + lrow, gcol = n0 + ch * 16;
       if (grow < p.M && gcol < p.N) {
+        size_t orow = (size_t)grow;
+        if (p.ob > 0) {  // physically padded NHWC output: interior pixel (oh + ob, ow + ob)
+          const int P = p.OH * p.OW;
+          const int img = grow / P, rem = grow - img * P;
+          const int oh = rem / p.OW, ow = rem - oh * p.OW;
+          orow = ((size_t)img * p.OHp + oh + p.ob) * p.OWp + ow + p.ob;
+        }
         const uint32_t* s = reinterpret_cast<const uint32_t*>(smem + lrow * SROW + ch * 16);
-        *reinterpret_cast<uint4*>(p.out + (size_t)grow * p.N + gcol) = make_uint4(s[0], s[1], s[2], s[3]);
+        *reinterpret_cast<uint4*>(p.out + orow * p.N + gcol) = make_uint4(s[0], s[1], s[2], s[3]);
       }
     }
   } else {
@@ -299,24 +313,24 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
   }
 }
 
-// ---- max-pool over NHWC u8 (src/functional.cc:36-64 on the internal layout) ---------
-// one thread = 16 channels of one output pixel; running max from 0, floor, no padding
+// ---- max-pool over (optionally bordered) NHWC u8: src/functional.cc:36-64 on the internal layout
 __device__ __forceinline__ uint32_t bmax4(uint32_t a, uint32_t b) {
-  // per-byte unsigned max: split even/odd bytes into 16-bit lanes
+  // per-byte unsigned max via 16-bit lanes (even / odd bytes)
   const uint32_t ae = a & 0x00FF00FFu, ao = (a >> 8) & 0x00FF00FFu;
   const uint32_t be = b & 0x00FF00FFu, bo = (b >> 8) & 0x00FF00FFu;
-  const uint32_t d = (ae | 0x01000100u) - be;                   // borrow-free per lane: bit 8 set iff ae >= be
-  const uint32_t me = ((d >> 8) & 0x00010001u) * 0xFFu;          // 0xFF where ae >= be
-  const uint32_t d2 = (ao | 0x01000100u) - bo;
-  const uint32_t mo = ((d2 >> 8) & 0x00010001u) * 0xFFu;
+  const uint32_t dev = (ae | 0x01000100u) - be;  // bit 8 of each 16-bit lane set iff a >= b
+  const uint32_t dod = (ao | 0x01000100u) - bo;
+  const uint32_t me = ((dev >> 8) & 0x00010001u) * 0xFFu;
+  const uint32_t mo = ((dod >> 8) & 0x00010001u) * 0xFFu;
   const uint32_t re = (ae & me) | (be & ~me & 0x00FF00FFu);
   const uint32_t ro = (ao & mo) | (bo & ~mo & 0x00FF00FFu);
   return re | (ro << 8);
 }
 
 __global__ __launch_bounds__(256) void maxpool_u8_nhwc_kernel(const uint8_t* __restrict__ in,
-                                                              uint8_t* __restrict__ out, int64_t total, int h,
-                                                              int w, int c16, int oh, int ow, int k, int s) {
+                                                              uint8_t* __restrict__ out, int64_t total, int inHp,
+                                                              int inWp, int ib, int c16, int oh, int ow, int k, int s,
+                                                              int outHp, int outWp, int ob, uint32_t lo4) {
   const int64_t gstride = (int64_t)gridDim.x * 256;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += gstride) {
     const int cc = (int)(e % c16);
@@ -325,46 +339,86 @@ __global__ __launch_bounds__(256) void maxpool_u8_nhwc_kernel(const uint8_t* __r
     t /= ow;
     const int y = (int)(t % oh);
     const int64_t img = t / oh;
-    const uint4* p = reinterpret_cast<const uint4*>(in) + ((img * h + (int64_t)y * s) * w + (int64_t)x * s) * c16 + cc;
-    uint4 m = make_uint4(0, 0, 0, 0);
+    const uint4* p = reinterpret_cast<const uint4*>(in) +
+                     ((img * inHp + (int64_t)y * s + ib) * inWp + (int64_t)x * s + ib) * c16 + cc;
+    uint4 m = make_uint4(lo4, lo4, lo4, lo4);  // 0 (reference's running max start), or zp when relu is folded in
     for (int a = 0; a < k; ++a)
       for (int b = 0; b < k; ++b) {
-        const uint4 v = p[((int64_t)a * w + b) * c16];
+        const uint4 v = p[((int64_t)a * inWp + b) * c16];
         m.x = bmax4(m.x, v.x);
         m.y = bmax4(m.y, v.y);
         m.z = bmax4(m.z, v.z);
         m.w = bmax4(m.w, v.w);
       }
-    reinterpret_cast<uint4*>(out)[e] = m;
+    reinterpret_cast<uint4*>(out)[((img * outHp + y + ob) * outWp + x + ob) * c16 + cc] = m;
   }
 }
 
-// ---- layout conversion u8: NCHW <-> NHWC through a 32 x 32 LDS tile per (image) --------
-// src [R][S] -> dst [S][R] per image (NCHW->NHWC: R = c, S = h*w; NHWC->NCHW: R = h*w, S = c)
+// ---- layout conversion u8 through a 64 x 64 LDS tile per image ---------------------------------
+// "planar" side: [R][S] contiguous per image (NCHW: R = c, S = h*w).  "pixel" side: NHWC with an
+// optional physical border: pixel s lives at row ((s / W + b) * Wp + s % W + b), pitch R bytes.
+template <bool TO_NHWC>
 __global__ __launch_bounds__(256) void transpose_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                           int R, int S) {
+                                                           int R, int S, int W, int Wp, int b, int64_t img_rows_p) {
   __shared__ uint8_t tile[64][65];
   const int64_t img = blockIdx.z;
   const int r0 = blockIdx.y * 64, s0 = blockIdx.x * 64;
-  const uint8_t* src = in + img * (int64_t)R * S;
-  uint8_t* dst = out + img * (int64_t)R * S;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int j = ty; j < 64; j += 4) {
-    const int r = r0 + j, s = s0 + tx;
-    tile[j][tx] = (r < R && s < S) ? src[(int64_t)r * S + s] : 0;
-  }
-  __syncthreads();
-  for (int j = ty; j < 64; j += 4) {
-    const int s = s0 + j, r = r0 + tx;
-    if (r < R && s < S) dst[(int64_t)s * R + r] = tile[tx][j];
+  auto prow = [&](int s) -> int64_t { return ((int64_t)(s / W + b) * Wp + (s % W) + b); };
+  if (TO_NHWC) {
+    const uint8_t* src = in + img * (int64_t)R * S;
+    uint8_t* dst = out + img * img_rows_p * R;
+    for (int j = ty; j < 64; j += 4) {
+      const int r = r0 + j, s = s0 + tx;
+      tile[j][tx] = (r < R && s < S) ? src[(int64_t)r * S + s] : 0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+      const int s = s0 + j, r = r0 + tx;
+      if (r < R && s < S) dst[prow(s) * R + r] = tile[tx][j];
+    }
+  } else {
+    const uint8_t* src = in + img * img_rows_p * R;
+    uint8_t* dst = out + img * (int64_t)R * S;
+    for (int j = ty; j < 64; j += 4) {
+      const int s = s0 + j, r = r0 + tx;
+      tile[j][tx] = (r < R && s < S) ? src[prow(s) * R + r] : 0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+      const int r = r0 + j, s = s0 + tx;
+      if (r < R && s < S) dst[(int64_t)r * S + s] = tile[tx][j];
+    }
   }
 }
 
-// ---- small-C repack: NCHW u8 [n][c<=4][h][w] -> physically padded "grouped" NHWC -------
-// out [n][Hp][Wg][16]: pixel (y, x) of the padded image (pad rows/cols hold the zero
-// point; x = 4*g + px) stores its channels at bytes 4*px .. 4*px+3 of group g (channels
-// >= c hold zp; their weights are zero).  Makes the stride-4 11x11x3 first layer an
-// ordinary C=16, 11x3-tap implicit GEMM with 16-byte-aligned, predicate-free gathers.
+// NHWC (border ib) -> NHWC (border ob >= 0), border bytes = zp; one thread per 16-B chunk of dst
+__global__ __launch_bounds__(256) void reborder_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                          int64_t total, int h, int w, int c16, int ib, int ob,
+                                                          uint32_t zp4) {
+  const int inHp = h + 2 * ib, inWp = w + 2 * ib, oHp = h + 2 * ob, oWp = w + 2 * ob;
+  (void)inHp;
+  const int64_t gstride = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += gstride) {
+    const int cc = (int)(e % c16);
+    int64_t t = e / c16;
+    const int xp = (int)(t % oWp);
+    t /= oWp;
+    const int yp = (int)(t % oHp);
+    const int64_t img = t / oHp;
+    const int y = yp - ob, x = xp - ob;
+    uint4 v = make_uint4(zp4, zp4, zp4, zp4);
+    if (y >= 0 && y < h && x >= 0 && x < w)
+      v = reinterpret_cast<const uint4*>(in)[((img * (h + 2 * ib) + y + ib) * inWp + x + ib) * c16 + cc];
+    reinterpret_cast<uint4*>(out)[e] = v;
+  }
+}
+
+// ---- small-C repack: NCHW u8 [n][c<=4][h][w] -> physically padded "grouped" NHWC -----------------
+// out [n][Hp][Wg][16]: pixel (y, x) of the padded image (pad rows/cols hold the zero point;
+// x = 4*g + px) stores its channels at bytes 4*px .. 4*px+3 of group g (channels >= c hold zp;
+// their weights are zero).  Makes the stride-4 11x11x3 first layer an ordinary C=16, 11x3-tap
+// implicit GEMM with 16-byte-aligned, predicate-free gathers.
 __global__ __launch_bounds__(256) void repack_smallc_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                             int64_t total, int c, int h, int w, int Hp, int Wg,
                                                             int ph, int pw, uint32_t zp) {
@@ -410,43 +464,53 @@ inline int cap_grid(int64_t items, int threads, int max_blocks = 256 * 16) {
   return (int)(b > max_blocks ? max_blocks : b);
 }
 
-template <int AMODE, int WM, int WN, int TM, int TN>
-int launch_cfg(i8ie_ctx* ctx, const IgemmArgs& a, const char* name, double ops, double bytes) {
+template <int AMODE, int WM, int WN, int TM, int TN, bool BIAS, bool ACC>
+int launch_cfg(i8ie_ctx* ctx, const IgemmArgs& a, const char* name, int kbytes, double ops, double bytes) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const int m_fastest = ((size_t)a.N > (size_t)a.M) ? 1 : 0;
-  I8ieProfScope prof(ctx, name, ops, bytes);
-  igemm_u8s8_kernel<AMODE, WM, WN, TM, TN><<<tiles_m * tiles_n, WM * WN * 64, 0, ctx->stream>>>(a, tiles_m, tiles_n,
-                                                                                              m_fastest);
+  char tag[64];
+  snprintf(tag, sizeof(tag), "%s|M%d,N%d,K%d", name, a.M, a.N, kbytes);
+  I8ieProfScope prof(ctx, ctx->prof ? tag : name, ops, bytes);
+  igemm_u8s8_kernel<AMODE, WM, WN, TM, TN, BIAS, ACC>
+      <<<tiles_m * tiles_n, WM * WN * 64, 0, ctx->stream>>>(a, tiles_m, tiles_n, m_fastest);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }
 
-template <int AMODE>
-int launch_any(i8ie_ctx* ctx, const IgemmArgs& a, double ops, double bytes) {
-  if (a.N <= 32) return launch_cfg<AMODE, 4, 1, 1, 1>(ctx, a, AMODE ? "igemm_conv_128x32" : "igemm_lin_128x32", ops, bytes);
-  if (a.N <= 64) return launch_cfg<AMODE, 2, 2, 2, 1>(ctx, a, AMODE ? "igemm_conv_128x64" : "igemm_lin_128x64", ops, bytes);
-  if (a.N <= 96) return launch_cfg<AMODE, 4, 1, 1, 3>(ctx, a, AMODE ? "igemm_conv_128x96" : "igemm_lin_128x96", ops, bytes);
-  return launch_cfg<AMODE, 2, 2, 2, 2>(ctx, a, AMODE ? "igemm_conv_128x128" : "igemm_lin_128x128", ops, bytes);
+template <int AMODE, bool BIAS, bool ACC>
+int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, double bytes) {
+  if (a.N <= 32)
+    return launch_cfg<AMODE, 4, 1, 1, 1, BIAS, ACC>(ctx, a, AMODE ? "igemm_conv_128x32" : "igemm_lin_128x32", kbytes,
+                                                    ops, bytes);
+  if (a.N <= 64)
+    return launch_cfg<AMODE, 2, 2, 2, 1, BIAS, ACC>(ctx, a, AMODE ? "igemm_conv_128x64" : "igemm_lin_128x64", kbytes,
+                                                    ops, bytes);
+  if (a.N <= 96)
+    return launch_cfg<AMODE, 4, 1, 1, 3, BIAS, ACC>(ctx, a, AMODE ? "igemm_conv_128x96" : "igemm_lin_128x96", kbytes,
+                                                    ops, bytes);
+  return launch_cfg<AMODE, 2, 2, 2, 2, BIAS, ACC>(ctx, a, AMODE ? "igemm_conv_128x128" : "igemm_lin_128x128", kbytes,
+                                                  ops, bytes);
 }
 
 }  // namespace
 
 // ---- entry points used by i8ie_layer.hip ---------------------------------------------------
 struct I8ieIgemmCall {
-  const uint8_t* A;
+  const uint8_t* A;   // AMODE 0: [M][lda]; AMODE 1: window origin of pixel (0,0) in a bordered NHWC input
+  size_t a_bytes;     // bytes readable from A
   int amode;
   long lda;
   int M, Kchunks;
-  int H, W, C, KH, KW, sh, sw, ph, pw, OH, OW;
-  int zp_in;
+  int Hp, Wp, C, KH, KW, sh, sw, OH, OW;  // AMODE 1: physical input dims, kernel, strides, output dims
   const int8_t* B;
-  int Kpad, N;
+  int Kpad, Npad, N;
   const int32_t* ocp;
   const float* biasf;
   float s_in, s_w, s_out;
   int zp_out, relu;
   uint8_t* out;
+  int ob;  // physical border of the NHWC output (AMODE 1 only)
   int32_t* acc;
   double Ktrue;
 };
@@ -455,15 +519,23 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   I8IE_REQUIRE(c.M > 0 && c.N > 0 && c.Kpad > 0 && c.Kpad % BK2 == 0, "igemm dimensions");
   I8IE_REQUIRE((reinterpret_cast<uintptr_t>(c.A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(c.B) & 15u) == 0,
                "operands must be 16-byte aligned");
+  I8IE_REQUIRE(c.a_bytes < ((size_t)1 << 32) - 4096, "activation tensor must be < 4 GiB");
   IgemmArgs a{};
   a.A = c.A;
-  a.lda = c.lda;
+  a.a_bytes = (unsigned)c.a_bytes;
+  a.lda = (unsigned)c.lda;
   a.M = c.M;
-  a.Kchunks = c.Kchunks;
-  a.H = c.H; a.W = c.W; a.C16 = c.C / 16;
-  a.KH = c.KH; a.KW = c.KW; a.sh = c.sh; a.sw = c.sw; a.ph = c.ph; a.pw = c.pw; a.OH = c.OH; a.OW = c.OW;
-  a.zp_fill = (uint32_t)(c.zp_in & 0xFF) * 0x01010101u;
+  if (c.amode == 1) {
+    I8IE_REQUIRE(c.C % 16 == 0 && c.C > 0, "NHWC gather needs channels % 16 == 0");
+    a.C = (unsigned)c.C;
+    a.row_pitch = (unsigned)c.Wp * (unsigned)c.C;
+    a.img_pitch = (unsigned)c.Hp * a.row_pitch;
+    a.sh = c.sh; a.sw = c.sw; a.OH = c.OH; a.OW = c.OW;
+    a.RC = c.KW * (c.C / 16);
+    a.row_jump = a.row_pitch - (unsigned)a.RC * 16u;
+  }
   a.B = c.B;
+  a.b_bytes = (unsigned)((size_t)c.Npad * c.Kpad);
   a.Kpad = c.Kpad;
   a.N = c.N;
   a.ocp = c.ocp;
@@ -472,19 +544,26 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   const double ms = (double)c.s_in * (double)c.s_w / (double)c.s_out;
   a.rq.ms = (float)ms;
   // fast path only for ordinary positive finite scales; anything else takes the exact sequence
-  a.rq.fast = (c.s_in > 0 && c.s_w > 0 && c.s_out > 0 && ms > 1e-30 && ms < 1e30 && c.s_in < 1e30f && c.s_w < 1e30f &&
-               c.s_out < 1e30f && c.s_in > 1e-30f && c.s_w > 1e-30f && c.s_out > 1e-30f)
-                  ? 1 : 0;
-  a.zp_out = c.zp_out;
-  a.relu = c.relu;
-  a.vec_store = ((c.N & 15) == 0 && (reinterpret_cast<uintptr_t>(c.out) & 15u) == 0) ? 1 : 0;
+  a.rq.fast = (c.s_in > 1e-30f && c.s_w > 1e-30f && c.s_out > 1e-30f && c.s_in < 1e30f && c.s_w < 1e30f &&
+               c.s_out < 1e30f && ms > 1e-30 && ms < 1e30) ? 1 : 0;
+  a.relu_lo = c.relu ? c.zp_out : 0;
   a.out = c.out;
+  a.ob = c.amode == 1 ? c.ob : 0;
+  a.OHp = c.OH + 2 * a.ob;
+  a.OWp = c.OW + 2 * a.ob;
+  a.vec_store = ((c.N & 15) == 0 && (reinterpret_cast<uintptr_t>(c.out) & 15u) == 0) ? 1 : 0;
+  I8IE_REQUIRE(a.ob == 0 || a.vec_store, "bordered output needs N % 16 == 0");
   a.acc = c.acc;
   const double ops = 2.0 * c.M * c.N * c.Ktrue;
   const double bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
-  if (c.amode == 0) return launch_any<0>(ctx, a, ops, bytes);
-  I8IE_REQUIRE(c.C % 16 == 0 && c.C > 0, "NHWC gather needs channels % 16 == 0");
-  return launch_any<1>(ctx, a, ops, bytes);
+  const int kb = c.Kchunks * 16;
+  const bool bias = c.biasf != nullptr, accd = c.acc != nullptr;
+  if (c.amode == 0) {
+    if (bias)
+      return accd ? launch_tile<0, true, true>(ctx, a, kb, ops, bytes) : launch_tile<0, true, false>(ctx, a, kb, ops, bytes);
+    return accd ? launch_tile<0, false, true>(ctx, a, kb, ops, bytes) : launch_tile<0, false, false>(ctx, a, kb, ops, bytes);
+  }
+  return accd ? launch_tile<1, false, true>(ctx, a, kb, ops, bytes) : launch_tile<1, false, false>(ctx, a, kb, ops, bytes);
 }
 
 int i8ie_launch_finish_offsets(i8ie_ctx* ctx, const int32_t* oc, const int32_t* wsum, const int8_t* qb, float s_in,
@@ -494,10 +573,30 @@ int i8ie_launch_finish_offsets(i8ie_ctx* ctx, const int32_t* oc, const int32_t* 
   return I8IE_OK;
 }
 
-int i8ie_launch_transpose_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int R, int S) {
-  I8ieProfScope prof(ctx, "layout_transpose_u8", 0.0, 2.0 * n * (double)R * S);
-  dim3 grid((S + 63) / 64, (R + 63) / 64, n);
-  transpose_u8_kernel<<<grid, 256, 0, ctx->stream>>>(in, out, R, S);
+// NCHW [n][c][h][w]  <->  NHWC [n][h + 2b][w + 2b][c] (border bytes untouched when writing)
+int i8ie_launch_nchw_to_nhwc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int b) {
+  I8ieProfScope prof(ctx, "layout_nchw_to_nhwc", 0.0, 2.0 * n * (double)c * h * w);
+  dim3 grid((h * w + 63) / 64, (c + 63) / 64, n);
+  transpose_u8_kernel<true><<<grid, 256, 0, ctx->stream>>>(in, out, c, h * w, w, w + 2 * b, b,
+                                                           (int64_t)(h + 2 * b) * (w + 2 * b));
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+int i8ie_launch_nhwc_to_nchw(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int b) {
+  I8ieProfScope prof(ctx, "layout_nhwc_to_nchw", 0.0, 2.0 * n * (double)c * h * w);
+  dim3 grid((h * w + 63) / 64, (c + 63) / 64, n);
+  transpose_u8_kernel<false><<<grid, 256, 0, ctx->stream>>>(in, out, c, h * w, w, w + 2 * b, b,
+                                                            (int64_t)(h + 2 * b) * (w + 2 * b));
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+int i8ie_launch_reborder(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int ib, int ob,
+                         int zp) {
+  const int64_t total = (int64_t)n * (h + 2 * ob) * (w + 2 * ob) * (c / 16);
+  I8ieProfScope prof(ctx, "reborder_u8_nhwc", 0.0, (double)n * c * h * w + 16.0 * total);
+  reborder_u8_kernel<<<cap_grid(total, 256), 256, 0, ctx->stream>>>(in, out, total, h, w, c / 16, ib, ob,
+                                                                    (uint32_t)(zp & 0xFF) * 0x01010101u);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }
@@ -512,12 +611,14 @@ int i8ie_launch_repack_smallc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, in
   return I8IE_OK;
 }
 
-int i8ie_launch_maxpool_nhwc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int k, int s) {
+int i8ie_launch_maxpool_nhwc(i8ie_ctx* ctx, const uint8_t* in, int ib, uint8_t* out, int ob, int n, int c, int h,
+                             int w, int k, int s, int relu_zp) {
   const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
   const int64_t total = (int64_t)n * oh * ow * (c / 16);
   I8ieProfScope prof(ctx, "maxpool_u8_nhwc", 0.0, (double)n * c * h * w + 16.0 * total);
-  maxpool_u8_nhwc_kernel<<<cap_grid(total, 256, 256 * 32), 256, 0, ctx->stream>>>(in, out, total, h, w, c / 16, oh, ow,
-                                                                                 k, s);
+  maxpool_u8_nhwc_kernel<<<cap_grid(total, 256, 256 * 32), 256, 0, ctx->stream>>>(
+      in, out, total, h + 2 * ib, w + 2 * ib, ib, c / 16, oh, ow, k, s, oh + 2 * ob, ow + 2 * ob, ob,
+      (uint32_t)(relu_zp & 0xFF) * 0x01010101u);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }

@@ -26,25 +26,30 @@ int i8ie_launch_im2col(i8ie_ctx* ctx, const uint8_t* in, uint8_t* col, int n, in
                        int oh, int ow, int stride, int pad, int K, int Kpad, int zp);
 int i8ie_launch_finish_offsets(i8ie_ctx* ctx, const int32_t* oc, const int32_t* wsum, const int8_t* qb, float s_in,
                                int n, int32_t* ocp, float* biasf);
-int i8ie_launch_transpose_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int R, int S);
+int i8ie_launch_nchw_to_nhwc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int b);
+int i8ie_launch_nhwc_to_nchw(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int b);
+int i8ie_launch_reborder(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int ib, int ob,
+                         int zp);
 int i8ie_launch_repack_smallc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int Hp,
                               int Wg, int ph, int pw, int zp);
-int i8ie_launch_maxpool_nhwc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int k, int s);
+int i8ie_launch_maxpool_nhwc(i8ie_ctx* ctx, const uint8_t* in, int ib, uint8_t* out, int ob, int n, int c, int h,
+                             int w, int k, int s, int relu_zp);
 
 struct I8ieIgemmCall {
   const uint8_t* A;
+  size_t a_bytes;
   int amode;
   long lda;
   int M, Kchunks;
-  int H, W, C, KH, KW, sh, sw, ph, pw, OH, OW;
-  int zp_in;
+  int Hp, Wp, C, KH, KW, sh, sw, OH, OW;
   const int8_t* B;
-  int Kpad, N;
+  int Kpad, Npad, N;
   const int32_t* ocp;
   const float* biasf;
   float s_in, s_w, s_out;
   int zp_out, relu;
   uint8_t* out;
+  int ob;
   int32_t* acc;
   double Ktrue;
 };
@@ -258,23 +263,33 @@ int i8ie_conv2d_u8s8(i8ie_ctx* ctx, const uint8_t* in, int n, int c, int h, int 
 }
 
 // ---- NHWC helpers exposed on the ABI -----------------------------------------------------------
-int i8ie_layout_convert_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int to_nhwc) {
+int i8ie_layout_convert_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int to_nhwc,
+                           int border, uint8_t border_value) {
   I8IE_REQUIRE(ctx && in && out, "null argument");
-  I8IE_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, "non-positive dimension");
+  I8IE_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && border >= 0, "bad dimension");
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
-  if (to_nhwc) return i8ie_launch_transpose_u8(ctx, in, out, n, c, h * w);
-  return i8ie_launch_transpose_u8(ctx, in, out, n, h * w, c);
+  if (to_nhwc) {
+    if (border > 0)
+      I8IE_HIP_TRY(hipMemsetAsync(out, border_value, (size_t)n * (h + 2 * border) * (w + 2 * border) * c, ctx->stream));
+    return i8ie_launch_nchw_to_nhwc(ctx, in, out, n, c, h, w, border);
+  }
+  return i8ie_launch_nhwc_to_nchw(ctx, in, out, n, c, h, w, border);
 }
 
-int i8ie_maxpool2d_u8_nhwc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int k, int s) {
+int i8ie_maxpool2d_u8_nhwc(i8ie_ctx* ctx, const uint8_t* in, int in_border, uint8_t* out, int out_border, int n,
+                           int c, int h, int w, int k, int s, uint8_t border_value) {
   I8IE_REQUIRE(ctx && in && out, "null argument");
-  I8IE_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, "non-positive dimension");
+  I8IE_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && in_border >= 0 && out_border >= 0, "bad dimension");
   I8IE_REQUIRE(c % 16 == 0, "NHWC max-pool needs channels % 16 == 0");
   I8IE_REQUIRE(k > 0 && s > 0, "kernel_size and stride must be positive");
   I8IE_REQUIRE(k <= h && k <= w, "window larger than the input");
   I8IE_REQUIRE(aligned16(in) && aligned16(out), "buffers must be 16-byte aligned");
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
-  return i8ie_launch_maxpool_nhwc(ctx, in, out, n, c, h, w, k, s);
+  const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
+  if (out_border > 0)
+    I8IE_HIP_TRY(hipMemsetAsync(out, border_value, (size_t)n * (oh + 2 * out_border) * (ow + 2 * out_border) * c,
+                                ctx->stream));
+  return i8ie_launch_maxpool_nhwc(ctx, in, in_border, out, out_border, n, c, h, w, k, s, 0);
 }
 
 // ---- layer handles ----------------------------------------------------------------------------
@@ -374,18 +389,29 @@ int i8ie_layer_preferred_layout(const i8ie_layer* L, int* layout) {
   return I8IE_OK;
 }
 
-int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, int m, int h, int w, float s_in,
-                             uint8_t zp_in, int relu, uint8_t* out, int out_layout, int32_t* acc) {
+int i8ie_layer_padding(const i8ie_layer* L, int* pad) {
+  I8IE_REQUIRE(L && pad, "null argument");
+  *pad = L->conv ? L->pad : 0;
+  return I8IE_OK;
+}
+
+int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, int in_border, int m, int h, int w,
+                             float s_in, uint8_t zp_in, int relu, uint8_t* out, int out_layout, int out_border,
+                             int32_t* acc) {
   I8IE_REQUIRE(L && in && out, "null argument");
   I8IE_REQUIRE(m > 0, "non-positive batch");
   I8IE_REQUIRE((in_layout == I8IE_LAYOUT_NCHW || in_layout == I8IE_LAYOUT_NHWC) &&
                    (out_layout == I8IE_LAYOUT_NCHW || out_layout == I8IE_LAYOUT_NHWC),
                "bad layout tag");
+  I8IE_REQUIRE(in_border >= 0 && out_border >= 0, "negative border");
+  I8IE_REQUIRE(in_layout == I8IE_LAYOUT_NHWC || in_border == 0, "only NHWC tensors carry a border");
+  I8IE_REQUIRE(out_layout == I8IE_LAYOUT_NHWC || out_border == 0, "only NHWC tensors carry a border");
   i8ie_ctx* ctx = L->ctx;
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
   I8IE_TRY(ensure_offsets(L, s_in, zp_in));
 
   if (!L->conv) {  // ---- Linear: row-major in / out, layouts do not apply -----------------------
+    I8IE_REQUIRE(in_border == 0 && out_border == 0, "Linear tensors carry no border");
     const bool need_pad = (L->K % 16 != 0) || !aligned16(in);
     if (force_fallback(ctx)) {
       if (need_pad) I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->Kpad));
@@ -406,10 +432,11 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
       c.lda = L->K;
       c.Kchunks = L->K / 16;
     }
-    c.amode = 0; c.M = m; c.zp_in = zp_in;
-    c.B = L->Bpack; c.Kpad = L->Kpad; c.N = L->n; c.ocp = L->ocp; c.biasf = L->biasf;
+    c.a_bytes = (size_t)m * c.lda;
+    c.amode = 0; c.M = m;
+    c.B = L->Bpack; c.Kpad = L->Kpad; c.Npad = L->Npad; c.N = L->n; c.ocp = L->ocp; c.biasf = L->biasf;
     c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
-    c.out = out; c.acc = acc; c.Ktrue = L->K;
+    c.out = out; c.ob = 0; c.acc = acc; c.Ktrue = L->K;
     return i8ie_igemm_launch(ctx, c);
   }
 
@@ -418,6 +445,7 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
   const size_t in_bytes = (size_t)m * cg.c * cg.h * cg.w;
   const size_t out_bytes = (size_t)m * cg.kc * cg.oh * cg.ow;
+  const size_t out_phys = (size_t)m * cg.kc * (cg.oh + 2 * out_border) * (cg.ow + 2 * out_border);
   const int path = force_fallback(ctx) ? PATH_F : L->path;
 
   if (path == PATH_F) {
@@ -430,37 +458,52 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
     uint8_t* col = ws;
     const uint8_t* src = in;
     if (a_bytes) {
-      I8IE_TRY(i8ie_launch_transpose_u8(ctx, in, ws + col_bytes, m, cg.h * cg.w, cg.c));
+      I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, in, ws + col_bytes, m, cg.c, cg.h, cg.w, in_border));
       src = ws + col_bytes;
     }
     uint8_t* dst = o_bytes ? ws + col_bytes + a_bytes : out;
     I8IE_TRY(conv_run_v1(ctx, src, m, cg, L->Bpack, L->oc, L->wsum, zp_in, s_in, L->s_w, L->s_out, L->zp_out, dst, acc,
                          col, ipc));
     if (relu) I8IE_TRY(i8ie_relu_u8(ctx, dst, dst, (int64_t)out_bytes, L->zp_out));
-    if (o_bytes) I8IE_TRY(i8ie_launch_transpose_u8(ctx, dst, out, m, cg.kc, cg.oh * cg.ow));
+    if (o_bytes) {
+      if (out_border > 0) I8IE_HIP_TRY(hipMemsetAsync(out, L->zp_out, out_phys, ctx->stream));
+      I8IE_TRY(i8ie_launch_nchw_to_nhwc(ctx, dst, out, m, cg.kc, cg.oh, cg.ow, out_border));
+    }
     return I8IE_OK;
   }
 
   I8ieIgemmCall c{};
-  c.amode = 1; c.M = m * cg.oh * cg.ow; c.zp_in = zp_in;
-  c.B = L->Bpack2; c.Kpad = L->Kpad2; c.Kchunks = L->K2 / 16; c.N = L->n; c.ocp = L->ocp; c.biasf = nullptr;
+  c.amode = 1; c.M = m * cg.oh * cg.ow;
+  c.B = L->Bpack2; c.Kpad = L->Kpad2; c.Npad = L->Npad; c.Kchunks = L->K2 / 16; c.N = L->n; c.ocp = L->ocp;
+  c.biasf = nullptr;
   c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
   c.acc = acc; c.Ktrue = cg.K; c.OH = cg.oh; c.OW = cg.ow;
   const size_t o_bytes = out_layout == I8IE_LAYOUT_NCHW ? i8ie_align_up(out_bytes, 256) : 0;
 
   if (path == PATH_A) {
-    const size_t a_bytes = in_layout == I8IE_LAYOUT_NCHW ? i8ie_align_up(in_bytes, 256) : 0;
+    const int Hp = cg.h + 2 * cg.pad, Wp = cg.w + 2 * cg.pad;
+    const bool direct = in_layout == I8IE_LAYOUT_NHWC && in_border >= cg.pad && aligned16(in);
+    const size_t a_bytes = direct ? 0 : i8ie_align_up((size_t)m * Hp * Wp * cg.c, 256);
     I8IE_TRY(i8ie_ws_reserve(ctx, a_bytes + o_bytes + 256));
     uint8_t* ws = (uint8_t*)ctx->ws;
-    if (a_bytes) {
-      I8IE_TRY(i8ie_launch_transpose_u8(ctx, in, ws, m, cg.c, cg.h * cg.w));
-      c.A = ws;
+    if (direct) {
+      const int iHp = cg.h + 2 * in_border, iWp = cg.w + 2 * in_border, d = in_border - cg.pad;
+      const size_t shift = ((size_t)d * iWp + d) * cg.c;
+      c.A = in + shift;
+      c.a_bytes = (size_t)m * iHp * iWp * cg.c - shift;
+      c.Hp = iHp; c.Wp = iWp;
     } else {
-      I8IE_REQUIRE(aligned16(in), "NHWC input must be 16-byte aligned");
-      c.A = in;
+      if (in_layout == I8IE_LAYOUT_NHWC) {
+        I8IE_TRY(i8ie_launch_reborder(ctx, in, ws, m, cg.c, cg.h, cg.w, in_border, cg.pad, zp_in));
+      } else {
+        if (cg.pad > 0) I8IE_HIP_TRY(hipMemsetAsync(ws, zp_in, (size_t)m * Hp * Wp * cg.c, ctx->stream));
+        I8IE_TRY(i8ie_launch_nchw_to_nhwc(ctx, in, ws, m, cg.c, cg.h, cg.w, cg.pad));
+      }
+      c.A = ws;
+      c.a_bytes = (size_t)m * Hp * Wp * cg.c;
+      c.Hp = Hp; c.Wp = Wp;
     }
-    c.H = cg.h; c.W = cg.w; c.C = cg.c; c.KH = cg.kh; c.KW = cg.kw;
-    c.sh = c.sw = cg.stride; c.ph = c.pw = cg.pad;
+    c.C = cg.c; c.KH = cg.kh; c.KW = cg.kw; c.sh = c.sw = cg.stride;
     c.out = o_bytes ? ws + a_bytes : out;
   } else {  // PATH_B: small-C, stride % 4 == 0
     const int Hp = (cg.oh - 1) * cg.stride + cg.kh;
@@ -471,24 +514,27 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
     uint8_t* ws = (uint8_t*)ctx->ws;
     const uint8_t* src = in;
     if (t_bytes) {
-      I8IE_TRY(i8ie_launch_transpose_u8(ctx, in, ws, m, cg.h * cg.w, cg.c));
+      I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, in, ws, m, cg.c, cg.h, cg.w, in_border));
       src = ws;
     }
     uint8_t* rep = ws + t_bytes;
     I8IE_TRY(i8ie_launch_repack_smallc(ctx, src, rep, m, cg.c, cg.h, cg.w, Hp, Wg, cg.pad, cg.pad, zp_in));
     c.A = rep;
-    c.H = Hp; c.W = Wg; c.C = 16; c.KH = cg.kh; c.KW = L->kwg;
-    c.sh = cg.stride; c.sw = cg.stride / 4; c.ph = c.pw = 0;
+    c.a_bytes = (size_t)m * Hp * Wg * 16;
+    c.Hp = Hp; c.Wp = Wg; c.C = 16; c.KH = cg.kh; c.KW = L->kwg;
+    c.sh = cg.stride; c.sw = cg.stride / 4;
     c.out = o_bytes ? ws + t_bytes + r_bytes : out;
   }
+  c.ob = o_bytes ? 0 : out_border;
+  if (!o_bytes && out_border > 0) I8IE_HIP_TRY(hipMemsetAsync(out, L->zp_out, out_phys, ctx->stream));
   I8IE_TRY(i8ie_igemm_launch(ctx, c));
-  if (o_bytes) I8IE_TRY(i8ie_launch_transpose_u8(ctx, c.out, out, m, cg.oh * cg.ow, cg.kc));
+  if (o_bytes) I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, c.out, out, m, cg.kc, cg.oh, cg.ow, 0));
   return I8IE_OK;
 }
 
 int i8ie_layer_forward(i8ie_layer* L, const uint8_t* in, int m, int h, int w, float s_in, uint8_t zp_in, uint8_t* out,
                        int32_t* acc) {
-  return i8ie_layer_forward_fused(L, in, I8IE_LAYOUT_NCHW, m, h, w, s_in, zp_in, 0, out, I8IE_LAYOUT_NCHW, acc);
+  return i8ie_layer_forward_fused(L, in, I8IE_LAYOUT_NCHW, 0, m, h, w, s_in, zp_in, 0, out, I8IE_LAYOUT_NCHW, 0, acc);
 }
 
 int i8ie_layer_destroy(i8ie_layer* L) {

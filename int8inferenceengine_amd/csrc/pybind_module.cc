@@ -81,15 +81,24 @@ struct Storage {
   // physical layout of a 4-D u8 activation: the engine keeps NHWC between layers and
   // converts back to the reference's NCHW only when the bytes are observed
   int layout = I8IE_LAYOUT_NCHW;
+  int border = 0;                      // NHWC only: physical border (pixels) holding the zero point
   int dn = 0, dc = 0, dh = 0, dw = 0;  // logical NCHW dims, valid when layout == NHWC
+  void set_nhwc(const std::vector<ssize_t>& shp, int b) {
+    layout = I8IE_LAYOUT_NHWC;
+    border = b;
+    dn = (int)shp[0]; dc = (int)shp[1]; dh = (int)shp[2]; dw = (int)shp[3];
+  }
   void to_nchw() {
     if (layout == I8IE_LAYOUT_NCHW) return;
     void* fresh = nullptr;
-    check(i8ie_malloc(ctx(), bytes, &fresh));
-    check(i8ie_layout_convert_u8(ctx(), (const uint8_t*)dev, (uint8_t*)fresh, dn, dc, dh, dw, 0));
+    const size_t logical = (size_t)dn * dc * dh * dw;
+    check(i8ie_malloc(ctx(), logical, &fresh));
+    check(i8ie_layout_convert_u8(ctx(), (const uint8_t*)dev, (uint8_t*)fresh, dn, dc, dh, dw, 0, border, 0));
     i8ie_free(ctx(), dev);  // stream-ordered: the conversion above still reads it, reuse is queued behind
     dev = fresh;
+    bytes = logical;
     layout = I8IE_LAYOUT_NCHW;
+    border = 0;
   }
   ~Storage() {
     if (dev && rt().ctx) i8ie_free(rt().ctx, dev);
@@ -135,12 +144,13 @@ struct Tensor {
   u8_t zero_point = 0;  // include/tensor.h:154
   // A layer forward that has been recorded but not launched yet: lets a following relu
   // fold into the epilogue.  Launching is observationally identical to the eager call.
-  std::shared_ptr<std::function<std::shared_ptr<Storage>(bool)>> pend;
+  // arguments: fuse relu; physical border wanted by the consumer (honoured for NHWC results)
+  std::shared_ptr<std::function<std::shared_ptr<Storage>(bool, int)>> pend;
   bool pend_relu = false;
 
-  void realize() {
+  void realize(int border = 0) {
     if (!pend) return;
-    st = (*pend)(pend_relu);
+    st = (*pend)(pend_relu, border);
     pend.reset();
   }
 
@@ -269,9 +279,11 @@ Tensor<u8_t> relu_u8(Tensor<u8_t>& in) {  // src/functional.cc:15-26
   Tensor<u8_t> out(in.shape);
   out.scale = in.scale;
   out.zero_point = in.zero_point;
-  out.st->layout = in.st->layout;  // elementwise: layout carries over
-  out.st->dn = in.st->dn; out.st->dc = in.st->dc; out.st->dh = in.st->dh; out.st->dw = in.st->dw;
-  check(i8ie_relu_u8(ctx(), src, out.dptr_any(), in.size, in.zero_point));
+  if (in.st->layout == I8IE_LAYOUT_NHWC) {  // elementwise over the physical buffer (border bytes = zp stay zp)
+    out.st = device_storage(in.st->bytes);
+    out.st->set_nhwc(in.shape, in.st->border);
+  }
+  check(i8ie_relu_u8(ctx(), src, (uint8_t*)out.st->dev, (int64_t)in.st->bytes, in.zero_point));
   return out;
 }
 Tensor<float> relu_f32(Tensor<float>& in) {  // src/functional.cc:5-13
@@ -287,20 +299,36 @@ std::vector<ssize_t> pool_shape(const Tensor<T>& in, ssize_t k, ssize_t s) {
   return {in.shape[0], in.shape[1], (in.shape[2] - k) / s + 1, (in.shape[3] - k) / s + 1};
 }
 Tensor<u8_t> max_pool2d_u8(Tensor<u8_t>& in, ssize_t k, ssize_t s) {  // src/functional.cc:36-64
-  Tensor<u8_t> out(pool_shape(in, k, s));
+  Tensor<u8_t> out;
+  out.shape = pool_shape(in, k, s);
+  out.size = 1;
+  for (ssize_t d : out.shape) out.size *= d;
   out.scale = in.scale;
   out.zero_point = in.zero_point;
-  const uint8_t* src = in.dptr_any();
-  if (in.st->layout == I8IE_LAYOUT_NHWC && in.shape[1] % 16 == 0) {
-    check(i8ie_maxpool2d_u8_nhwc(ctx(), src, out.dptr_any(), (int)in.shape[0], (int)in.shape[1], (int)in.shape[2],
-                                 (int)in.shape[3], (int)k, (int)s));
-    out.st->layout = I8IE_LAYOUT_NHWC;
-    out.st->dn = (int)out.shape[0]; out.st->dc = (int)out.shape[1]; out.st->dh = (int)out.shape[2];
-    out.st->dw = (int)out.shape[3];
-    return out;
-  }
-  check(i8ie_maxpool2d_u8(ctx(), in.dptr(), out.dptr(), (int)in.shape[0], (int)in.shape[1], (int)in.shape[2],
-                          (int)in.shape[3], (int)k, (int)s));
+  Tensor<u8_t> src = in;
+  const std::vector<ssize_t> ishp = in.shape, oshp = out.shape;
+  const u8_t zp = in.zero_point;
+  const int kk = (int)k, ss = (int)s;
+  // deferred so that a consuming conv can ask for a zero-point border around the result
+  out.pend = std::make_shared<std::function<std::shared_ptr<Storage>(bool, int)>>(
+      [src, ishp, oshp, zp, kk, ss](bool relu, int border) mutable {
+        const uint8_t* ip = src.dptr_any();
+        std::shared_ptr<Storage> st;
+        const size_t logical = (size_t)oshp[0] * oshp[1] * oshp[2] * oshp[3];
+        if (src.st->layout == I8IE_LAYOUT_NHWC && ishp[1] % 16 == 0) {
+          st = device_storage((size_t)oshp[0] * oshp[1] * (oshp[2] + 2 * border) * (oshp[3] + 2 * border));
+          check(i8ie_maxpool2d_u8_nhwc(ctx(), ip, src.st->border, (uint8_t*)st->dev, border, (int)ishp[0], (int)ishp[1],
+                                       (int)ishp[2], (int)ishp[3], kk, ss, zp));
+          st->set_nhwc(oshp, border);
+        } else {
+          st = device_storage(logical);
+          check(i8ie_maxpool2d_u8(ctx(), src.dptr(), (uint8_t*)st->dev, (int)ishp[0], (int)ishp[1], (int)ishp[2],
+                                  (int)ishp[3], kk, ss));
+        }
+        if (relu) check(i8ie_relu_u8(ctx(), (const uint8_t*)st->dev, (uint8_t*)st->dev, (int64_t)st->bytes, zp));
+        src = Tensor<u8_t>();
+        return st;
+      });
   return out;
 }
 Tensor<float> max_pool2d_f32(Tensor<float>& in, ssize_t k, ssize_t s) {
@@ -463,19 +491,29 @@ class BaseLayer {
     const u8_t zp_in = in.zero_point;
     const std::vector<ssize_t> oshp = out.shape;
     const size_t obytes = (size_t)out.size;
-    out.pend = std::make_shared<std::function<std::shared_ptr<Storage>(bool)>>(
-        [handle, src, s_in, zp_in, m, h, w, spatial, oshp, obytes](bool relu) mutable {
-          const uint8_t* ip = spatial ? src.dptr_any() : src.dptr();
-          const int in_layout = src.st->layout;
-          int out_layout = I8IE_LAYOUT_NCHW;
-          if (spatial) check(i8ie_layer_preferred_layout(handle.get(), &out_layout));
-          auto st = device_storage(obytes);
-          check(i8ie_layer_forward_fused(handle.get(), ip, in_layout, m, h, w, s_in, zp_in, relu ? 1 : 0,
-                                         (uint8_t*)st->dev, out_layout, nullptr));
-          if (out_layout == I8IE_LAYOUT_NHWC) {
-            st->layout = I8IE_LAYOUT_NHWC;
-            st->dn = (int)oshp[0]; st->dc = (int)oshp[1]; st->dh = (int)oshp[2]; st->dw = (int)oshp[3];
+    out.pend = std::make_shared<std::function<std::shared_ptr<Storage>(bool, int)>>(
+        [handle, src, s_in, zp_in, m, h, w, spatial, oshp, obytes](bool relu, int border) mutable {
+          int out_layout = I8IE_LAYOUT_NCHW, pad = 0;
+          if (spatial) {
+            check(i8ie_layer_preferred_layout(handle.get(), &out_layout));
+            check(i8ie_layer_padding(handle.get(), &pad));
           }
+          const uint8_t* ip;
+          if (spatial) {
+            // ask a still-pending producer for a zero-point border that covers this conv's padding
+            src.realize(out_layout == I8IE_LAYOUT_NHWC ? pad : 0);
+            ip = src.dptr_any();
+          } else {
+            ip = src.dptr();
+          }
+          const int in_layout = src.st->layout, in_border = src.st->border;
+          const int ob = out_layout == I8IE_LAYOUT_NHWC ? border : 0;
+          const size_t phys = out_layout == I8IE_LAYOUT_NHWC
+                                  ? (size_t)oshp[0] * oshp[1] * (oshp[2] + 2 * ob) * (oshp[3] + 2 * ob) : obytes;
+          auto st = device_storage(phys);
+          check(i8ie_layer_forward_fused(handle.get(), ip, in_layout, in_border, m, h, w, s_in, zp_in, relu ? 1 : 0,
+                                         (uint8_t*)st->dev, out_layout, ob, nullptr));
+          if (out_layout == I8IE_LAYOUT_NHWC) st->set_nhwc(oshp, ob);
           src = Tensor<u8_t>();  // release the input as soon as the launch is queued
           return st;
         });

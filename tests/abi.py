@@ -226,35 +226,45 @@ class Ctx:
     def set_force_fallback(self, on):
         ck(lib().i8ie_ctx_set_option(self.h, 1, 1 if on else 0))
 
-    def layout_convert(self, q, to_nhwc):
-        """q is given/returned as numpy in the SOURCE/DEST physical layout."""
+    def layout_convert(self, q, to_nhwc, border=0, fill=0):
+        """NCHW numpy -> physical NHWC (with border) numpy, or back."""
         q = np.ascontiguousarray(q, np.uint8)
         if to_nhwc:
             n, c, h, w = q.shape
-            oshape = (n, h, w, c)
+            oshape = (n, h + 2 * border, w + 2 * border, c)
         else:
-            n, h, w, c = q.shape
+            n, hp, wp, c = q.shape
+            h, w = hp - 2 * border, wp - 2 * border
             oshape = (n, c, h, w)
         d, o = self.put(q), self.empty(oshape, np.uint8)
-        ck(lib().i8ie_layout_convert_u8(self.h, d.ptr, o.ptr, n, c, h, w, 1 if to_nhwc else 0))
+        ck(lib().i8ie_layout_convert_u8(self.h, d.ptr, o.ptr, n, c, h, w, 1 if to_nhwc else 0, border, C.c_uint8(fill)))
         r = o.get()
         d.free(); o.free()
         return r
 
-    def max_pool2d_nhwc(self, q_nhwc, k, s):
-        q = np.ascontiguousarray(q_nhwc, np.uint8)
-        n, h, w, c = q.shape
+    def max_pool2d_nhwc(self, q_phys, k, s, in_border=0, out_border=0, fill=0):
+        q = np.ascontiguousarray(q_phys, np.uint8)
+        n, hp, wp, c = q.shape
+        h, w = hp - 2 * in_border, wp - 2 * in_border
         oh, ow = (h - k) // s + 1, (w - k) // s + 1
-        d, o = self.put(q), self.empty((n, oh, ow, c), np.uint8)
-        ck(lib().i8ie_maxpool2d_u8_nhwc(self.h, d.ptr, o.ptr, n, c, h, w, k, s))
+        d, o = self.put(q), self.empty((n, oh + 2 * out_border, ow + 2 * out_border, c), np.uint8)
+        ck(lib().i8ie_maxpool2d_u8_nhwc(self.h, d.ptr, in_border, o.ptr, out_border, n, c, h, w, k, s, C.c_uint8(fill)))
         r = o.get()
         d.free(); o.free()
         return r
+
+    @staticmethod
+    def to_phys(q_nchw, border, fill):
+        """host-side NCHW -> bordered NHWC"""
+        n, c, h, w = q_nchw.shape
+        p = np.full((n, h + 2 * border, w + 2 * border, c), fill, np.uint8)
+        p[:, border:border + h, border:border + w, :] = q_nchw.transpose(0, 2, 3, 1)
+        return p
 
     def layer_forward_fused(self, kind, q_in_nchw, qw, qb, s_in, zp_in, s_w, s_out, zp_out, stride=1, pad=0,
-                            in_nhwc=False, out_nhwc=False, relu=False, want_acc=True):
-        """i8ie_layer_forward_fused.  Input is given in NCHW and converted on the host when in_nhwc;
-        the output is always returned in NCHW (converted back on the host when out_nhwc)."""
+                            in_nhwc=False, out_nhwc=False, relu=False, want_acc=True, in_border=0, out_border=0):
+        """i8ie_layer_forward_fused.  Input is given in NCHW and laid out on the host as asked (NHWC with a
+        zero-point border when in_nhwc); the output is returned in NCHW together with the raw physical array."""
         q_in = np.ascontiguousarray(q_in_nchw, np.uint8)
         qw = np.ascontiguousarray(qw, np.int8)
         qb = np.ascontiguousarray(qb, np.int8)
@@ -272,23 +282,31 @@ class Ctx:
             oh, ow = (h - kh + 2 * pad) // stride + 1, (w - kw + 2 * pad) // stride + 1
             ck(lib().i8ie_conv2d_create(self.h, qw.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p), kc, c,
                                         kh, kw, stride, pad, C.c_float(s_w), C.byref(L)))
-            oshape, ashape = (m, kc, oh, ow), (m, oh * ow, kc)
-            phys_in = np.ascontiguousarray(q_in.transpose(0, 2, 3, 1)) if in_nhwc else q_in
+            ashape = (m, oh * ow, kc)
+            oshape = (m, oh + 2 * out_border, ow + 2 * out_border, kc) if out_nhwc else (m, kc, oh, ow)
+            phys_in = self.to_phys(q_in, in_border, zp_in) if in_nhwc else q_in
         ck(lib().i8ie_layer_set_output_qparams(L, C.c_float(s_out), C.c_uint8(zp_out)))
         pref = C.c_int(-1)
         ck(lib().i8ie_layer_preferred_layout(L, C.byref(pref)))
         di = self.put(phys_in)
         out = self.empty(oshape, np.uint8)
         acc = self.empty(ashape, np.int32) if want_acc else None
-        ck(lib().i8ie_layer_forward_fused(L, di.ptr, 1 if in_nhwc else 0, m, h, w, C.c_float(s_in), C.c_uint8(zp_in),
-                                          1 if relu else 0, out.ptr, 1 if out_nhwc else 0,
-                                          acc.ptr if acc else None))
-        o = out.get()
+        ck(lib().i8ie_layer_forward_fused(L, di.ptr, 1 if in_nhwc else 0, in_border, m, h, w, C.c_float(s_in),
+                                          C.c_uint8(zp_in), 1 if relu else 0, out.ptr, 1 if out_nhwc else 0,
+                                          out_border, acc.ptr if acc else None))
+        phys = out.get()
+        o = phys
         if kind != "linear" and out_nhwc:
-            o = np.ascontiguousarray(o.reshape(oshape[0], oshape[2], oshape[3], oshape[1]).transpose(0, 3, 1, 2))
+            b = out_border
+            if b:
+                ring = phys.copy()
+                ring[:, b:-b, b:-b, :] = zp_out
+                assert (ring == zp_out).all(), "output border must hold zp_out"
+                o = phys[:, b:-b, b:-b, :]
+            o = np.ascontiguousarray(o.transpose(0, 3, 1, 2))
         r = (o, acc.get() if acc else None, pref.value)
         lib().i8ie_layer_destroy(L)
-        for b in (di, out, acc):
-            if b is not None:
-                b.free()
+        for bb in (di, out, acc):
+            if bb is not None:
+                bb.free()
         return r

@@ -228,15 +228,20 @@ FUSED_GEOMS = [
 
 
 @pytest.mark.parametrize("geom", FUSED_GEOMS)
-@pytest.mark.parametrize("layouts", [(False, False), (True, True), (False, True), (True, False)])
+@pytest.mark.parametrize("layouts", [(False, 0, False, 0), (True, 0, True, 0), (False, 0, True, 2), (True, 0, False, 0),
+                                     (True, "pad", True, 1), (True, "pad+1", True, 0)])
 def test_conv_fused_all_layouts(gpu, orc, geom, layouts):
     n, c, h, w, kc, k, stride, pad = geom
-    in_nhwc, out_nhwc = layouts
+    in_nhwc, ib, out_nhwc, ob = layouts
+    ib = {"pad": pad, "pad+1": pad + 1}.get(ib, ib)
+    if kc % 16 != 0:
+        ob = 0  # bordered NHWC outputs need features % 16 == 0
     cs = synth.conv_case(orc, 31 + sum(geom), n, c, h, w, kc, k, stride, pad)
     for relu in (False, True):
         out, acc, _ = gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"],
                                               cs["s_w"], cs["s_out"], cs["zp_out"], stride=stride, pad=pad,
-                                              in_nhwc=in_nhwc, out_nhwc=out_nhwc, relu=relu)
+                                              in_nhwc=in_nhwc, out_nhwc=out_nhwc, relu=relu, in_border=ib,
+                                              out_border=ob)
         want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
         assert np.array_equal(acc, cs["acc"])
         assert np.array_equal(out, want)
@@ -297,14 +302,17 @@ def test_layout_convert_and_nhwc_pool(gpu, orc):
     rng = np.random.default_rng(23)
     for shape in [(2, 96, 55, 55), (3, 256, 13, 13), (1, 16, 5, 7), (2, 3, 9, 9), (5, 130, 3, 2)]:
         q = rng.integers(0, 256, shape, dtype=np.uint8)
-        nhwc = gpu.layout_convert(q, True)
-        assert np.array_equal(nhwc, q.transpose(0, 2, 3, 1))
-        assert np.array_equal(gpu.layout_convert(nhwc, False), q)
+        for b in (0, 1, 2):
+            nhwc = gpu.layout_convert(q, True, border=b, fill=77)
+            assert np.array_equal(nhwc, gpu.to_phys(q, b, 77))
+            assert np.array_equal(gpu.layout_convert(nhwc, False, border=b), q)
     for shape, k, s in [((2, 96, 55, 55), 3, 2), ((2, 256, 27, 27), 3, 2), ((3, 256, 13, 13), 3, 2),
                         ((2, 32, 8, 8), 2, 2), ((1, 16, 4, 4), 2, 1), ((1, 16, 4, 4), 1, 2), ((2, 48, 7, 9), 3, 3)]:
         q = rng.integers(0, 256, shape, dtype=np.uint8)
-        got = gpu.max_pool2d_nhwc(np.ascontiguousarray(q.transpose(0, 2, 3, 1)), k, s)
-        assert np.array_equal(got.transpose(0, 3, 1, 2), orc.max_pool2d(q, k, s))
+        want = orc.max_pool2d(q, k, s)
+        for ib, ob in ((0, 0), (0, 2), (1, 1), (2, 0)):
+            got = gpu.max_pool2d_nhwc(gpu.to_phys(q, ib, 9), k, s, in_border=ib, out_border=ob, fill=200)
+            assert np.array_equal(got, gpu.to_phys(want, ob, 200))
 
 
 def test_conv_batch_invariance_fused_at_bench_size(gpu, orc):
@@ -316,5 +324,5 @@ def test_conv_batch_invariance_fused_at_bench_size(gpu, orc):
     big[-4:] = cs["q_in"]
     out, _, _ = gpu.layer_forward_fused("conv", big, cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
                                         cs["s_out"], cs["zp_out"], stride=1, pad=1, in_nhwc=True, out_nhwc=True,
-                                        want_acc=False)
+                                        want_acc=False, in_border=1, out_border=1)
     assert np.array_equal(out[:4], cs["out"]) and np.array_equal(out[-4:], cs["out"])
