@@ -55,6 +55,9 @@ int i8ie_sync(i8ie_ctx* ctx);
  * path (materialised im2col + v1 GEMM, separate ReLU) instead of the implicit-GEMM paths;
  * results are identical, it exists so that tests can cover both. */
 #define I8IE_OPT_FORCE_FALLBACK 1
+/* I8IE_OPT_KERNEL_VARIANT = 2 selects among compiled variants of the contraction kernel (all
+ * produce identical bytes; a tuning / A-B timing aid, 0 = default). */
+#define I8IE_OPT_KERNEL_VARIANT 2
 int i8ie_ctx_set_option(i8ie_ctx* ctx, int option, int value);
 
 /* Activation layouts accepted by the *_fused / *_nhwc entry points.  NCHW is the
@@ -75,7 +78,9 @@ typedef struct i8ie_profile_entry {
   double total_ops;
   double total_bytes;
 } i8ie_profile_entry;
-int i8ie_profile_start(i8ie_ctx* ctx);
+/* mfma_kernels_only != 0: bracket only the contraction kernels (those with algorithmic
+ * ops), which keeps the instrumentation overhead of a timed region small */
+int i8ie_profile_start(i8ie_ctx* ctx, int mfma_kernels_only);
 int i8ie_profile_stop(i8ie_ctx* ctx, i8ie_profile_entry* entries, int max_entries, int* n_entries);
 
 /* ---- device memory (replaces `new T[]` + py::capsule, include/tensor.h:26-61) */

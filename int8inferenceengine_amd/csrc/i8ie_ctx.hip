@@ -215,10 +215,11 @@ int i8ie_memory_stats(i8ie_ctx* ctx, size_t* bytes_live, size_t* bytes_cached, s
   return I8IE_OK;
 }
 
-int i8ie_profile_start(i8ie_ctx* ctx) {
+int i8ie_profile_start(i8ie_ctx* ctx, int mfma_kernels_only) {
   I8IE_REQUIRE(ctx != nullptr, "null ctx");
   if (!ctx->prof) ctx->prof = new (std::nothrow) I8ieProf();
   I8IE_REQUIRE(ctx->prof != nullptr, "out of host memory");
+  ctx->prof_mfma_only = mfma_kernels_only ? 1 : 0;
   return I8IE_OK;
 }
 

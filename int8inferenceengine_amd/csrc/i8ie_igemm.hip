@@ -49,24 +49,25 @@ __device__ __forceinline__ int requant_exact(float cf, const Requant& q, int lo)
   return u > lo ? u : lo;
 }
 
-// est = fma(cf, ms, zp), ms = fl(s_in*s_w/s_out).  While -1 < est < 256 the reference value
-// v obeys |v - est| < 9.2e-5 (reference: 3 roundings on |C*s_in*s_w/s_out| < 256 and one on
-// |v| < 257; est: one rounding of ms and one of the fma), so when est is further than
-// 2^-12 from an integer, v lies in the same unit interval and trunc + clamp of v equals
-// clamp(floor(est), 0, 255).  est <= -1 / est >= 256 clamp with the same margin.  Anything
-// closer to an integer takes the exact sequence.  `lo` folds relu (max with zp_out) in.
-__device__ __forceinline__ int requant(int c, const Requant& q, int lo) {
+// e = fma(cf, ms, zp - 0.5), ms = fl(s_in*s_w/s_out): an estimate of (reference value v) - 0.5.
+// While -1 < v < 256, |v - (e + 0.5)| < 9.2e-5 (reference: 3 roundings on |C*s_in*s_w/s_out| < 256
+// and one on |v| < 257; e: one rounding of ms, one of the fma).  So if e is further than 2^-12
+// from every half-integer, v lies strictly inside the unit interval [k, k+1) with k = rne(e), and
+// the reference's trunc + clamp equals sat_u8(rne(e)), which is exactly what v_cvt_pk_u8_f32
+// computes (round-to-nearest-even, saturate to [0, 255], insert into byte r).  Outside (-1, 256)
+// both sides clamp, with the same margin.  Anything closer to a half-integer replays the exact
+// sequence.  relu (max with zp_out) commutes with the monotone rounding: rne(max(e, lo)) for the
+// integer lo.
+__device__ __forceinline__ uint32_t requant_pack(int c, const Requant& q, int lo, float lof, int r, uint32_t packed) {
   const float cf = (float)c;
   if (q.fast) {
-    const float est = __builtin_fmaf(cf, q.ms, q.zpf);
-    const float fl = __builtin_floorf(est);
-    const float fr = est - fl;
-    if (__builtin_fabsf(fr - 0.5f) <= 0.5f - 2.44140625e-4f) {
-      const int k = (int)fl;  // saturating; |est| beyond int range is far outside [0, 255] anyway
-      return k < lo ? lo : (k > 255 ? 255 : k);
-    }
+    const float e = __builtin_fmaf(cf, q.ms, q.zpf - 0.5f);
+    const float fr = __builtin_amdgcn_fractf(e);
+    packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(e, lof), r, packed);
+    if (__builtin_fabsf(fr - 0.5f) >= 2.44140625e-4f) return packed;
   }
-  return requant_exact(cf, q, lo);
+  const uint32_t u = (uint32_t)requant_exact(cf, q, lo);
+  return (packed & ~(0xFFu << (8 * r))) | (u << (8 * r));
 }
 
 struct IgemmArgs {
@@ -97,16 +98,20 @@ struct IgemmArgs {
   int32_t* acc;  // [M][N]
 };
 
-template <int AMODE, int WM, int WN, int TM, int TN, bool BIAS, bool ACC>
+// VAR (tuning variants, identical results): 0 = two LDS stages, loads one K tile ahead;
+// 1 = loads two K tiles ahead (second register set); 2 = VAR 0 + s_setprio around the MFMAs;
+// 3 = one LDS stage, two barriers per K tile (half the LDS: more blocks per CU)
+template <int AMODE, int WM, int WN, int TM, int TN, bool BIAS, bool ACC, int VAR>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, int tiles_m, int tiles_n,
                                                                  int m_fastest) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+  constexpr int NST = VAR == 3 ? 1 : 2;
   constexpr int A_PER = BM * 8 / NT, B_PER = BN * 8 / NT;
   static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "staging map");
   constexpr int STAGE = (BM + BN) * LROW;
   constexpr int SROW = BN + 4;  // epilogue tile row stride: odd dword count -> conflict-free ds_write_b32
-  static_assert(BM * SROW <= 2 * STAGE, "epilogue tile fits");
-  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STAGE];
+  static_assert(BM * SROW <= NST * STAGE, "epilogue tile fits");
+  __shared__ __attribute__((aligned(16))) uint8_t smem[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int gcol = nb + (r & 3) + 8 * (r >> 2);
-      const int init = gcol < p.N ? p.ocp[gcol] : 0;
+      const int init = gcol < p.N ? p.ocp[gcol] : 0;  // (unconditional loads here make hipcc double the AGPRs)
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) acc[mi][ni][r] = init;
     }
@@ -177,13 +182,14 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
   }
 
   v4i ra[A_PER], rb[B_PER];
-  auto load_tile = [&](int k0) {
+  v4i ra2[VAR == 1 ? A_PER : 1], rb2[VAR == 1 ? B_PER : 1];  // second register set (VAR 1)
+  auto load_into = [&](int k0, v4i* da, v4i* db) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i)
-      ra[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i] + koff, 0, 0));
+      da[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i] + koff, 0, 0));
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
-      rb[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], k0, 0));
+      db[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], k0, 0));
     koff += BK2;
     if (AMODE == 1) {
       f += 8;
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
       }
     }
   };
+  auto load_tile = [&](int k0) { load_into(k0, ra, rb); };
 
   // LDS addresses (bytes from smem); stage s adds s * STAGE as an immediate
   int a_wr[A_PER], b_wr[B_PER], a_rd[TM], b_rd[TN];
@@ -209,65 +216,103 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
   for (int ni = 0; ni < TN; ++ni)
     b_rd[ni] = BM * LROW + ((wn * TN + ni) * 32 + (lane & 31)) * LROW + (lane >> 5) * 16;
 
-  auto store_tile = [&](auto sc) {
+  auto store_from = [&](auto sc, const v4i* sa, const v4i* sb) {
     constexpr int S = decltype(sc)::value;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i)
-      *reinterpret_cast<v4i*>(smem + S * STAGE + a_wr[i]) = ra[i] ^ (int)0x80808080;  // u8 -> s8
+      *reinterpret_cast<v4i*>(smem + S * STAGE + a_wr[i]) = sa[i] ^ (int)0x80808080;  // u8 -> s8
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) *reinterpret_cast<v4i*>(smem + S * STAGE + b_wr[i]) = rb[i];
+    for (int i = 0; i < B_PER; ++i) *reinterpret_cast<v4i*>(smem + S * STAGE + b_wr[i]) = sb[i];
   };
+  auto store_tile = [&](auto sc) { store_from(sc, ra, rb); };
   auto compute = [&](auto sc) {
     constexpr int S = decltype(sc)::value;
+    v4i af[2][TM], bf[2][TN];  // fragments of k-step ks+1 are fetched under the MFMAs of k-step ks
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) af[0][mi] = *reinterpret_cast<const v4i*>(smem + S * STAGE + a_rd[mi]);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) bf[0][ni] = *reinterpret_cast<const v4i*>(smem + S * STAGE + b_rd[ni]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      v4i af[TM], bf[TN];
+      if (ks < 3) {
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
-        af[mi] = *reinterpret_cast<const v4i*>(smem + S * STAGE + ks * 32 + a_rd[mi]);
+        for (int mi = 0; mi < TM; ++mi)
+          af[(ks + 1) & 1][mi] = *reinterpret_cast<const v4i*>(smem + S * STAGE + (ks + 1) * 32 + a_rd[mi]);
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni)
-        bf[ni] = *reinterpret_cast<const v4i*>(smem + S * STAGE + ks * 32 + b_rd[ni]);
+        for (int ni = 0; ni < TN; ++ni)
+          bf[(ks + 1) & 1][ni] = *reinterpret_cast<const v4i*>(smem + S * STAGE + (ks + 1) * 32 + b_rd[ni]);
+      }
+      if (VAR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ks & 1][ni], af[ks & 1][mi], acc[mi][ni], 0, 0, 0);
+      if (VAR == 2) __builtin_amdgcn_s_setprio(0);
     }
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
   const int nk = p.Kpad / BK2;
-  load_tile(0);
-  store_tile(S0{});
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 1 < nk) load_tile((kt + 1) * BK2);  // global loads in flight under the MFMAs
-    compute(S0{});
-    if (kt + 1 < nk) store_tile(S1{});
+  if constexpr (VAR == 3) {  // one stage: compute | barrier | refill | barrier
+    load_tile(0);
+    store_tile(S0{});
     __syncthreads();
-    if (kt + 1 >= nk) break;
-    if (kt + 2 < nk) load_tile((kt + 2) * BK2);
-    compute(S1{});
-    if (kt + 2 < nk) store_tile(S0{});
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) load_tile((kt + 1) * BK2);
+      compute(S0{});
+      __syncthreads();
+      if (kt + 1 < nk) {
+        store_tile(S0{});
+        __syncthreads();
+      }
+    }
+  } else if constexpr (VAR == 1) {  // loads run two K tiles ahead of the MFMAs
+    load_into(0, ra, rb);
+    store_from(S0{}, ra, rb);
+    if (nk > 1) load_into(BK2, ra2, rb2);
     __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) load_into((kt + 2) * BK2, ra, rb);
+      compute(S0{});
+      if (kt + 1 < nk) store_from(S1{}, ra2, rb2);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) load_into((kt + 3) * BK2, ra2, rb2);
+      compute(S1{});
+      if (kt + 2 < nk) store_from(S0{}, ra, rb);
+      __syncthreads();
+    }
+  } else {
+    load_tile(0);
+    store_tile(S0{});
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 1 < nk) load_tile((kt + 1) * BK2);  // global loads in flight under the MFMAs
+      compute(S0{});
+      if (kt + 1 < nk) store_tile(S1{});
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      if (kt + 2 < nk) load_tile((kt + 2) * BK2);
+      compute(S1{});
+      if (kt + 2 < nk) store_tile(S0{});
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: (bias) -> requant -> (relu) -> LDS tile [BM][BN] -> 16-B row stores ----
   const Requant rq = p.rq;
   const int lo = p.relu_lo;
+  const float lof = (float)lo;
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int lcol0 = (wn * TN + ni) * 32 + 8 * g + 4 * (lane >> 5);
       const int gcol0 = n0 + lcol0;
-      float bfv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (BIAS) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bfv[r] = gcol0 + r < p.N ? p.biasf[gcol0 + r] : 0.0f;
-      }
+      float4 bfv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (BIAS) bfv = *reinterpret_cast<const float4*>(p.biasf + gcol0);  // padded to Npad
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
         const int lrow = (wm * TM + mi) * 32 + (lane & 31);
@@ -279,8 +324,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
             const int grow = m0 + lrow, gcol = gcol0 + r;
             if (grow < p.M && gcol < p.N) p.acc[(size_t)grow * p.N + gcol] = c;
           }
-          if (BIAS) c = (int)((float)c + bfv[r]);  // src/fully_connected.cc:44: int += float
-          packed |= (uint32_t)requant(c, rq, lo) << (8 * r);
+          if (BIAS) c = (int)((float)c + (r == 0 ? bfv.x : r == 1 ? bfv.y : r == 2 ? bfv.z : bfv.w));  // src/fully_connected.cc:44
+          packed = requant_pack(c, rq, lo, lof, r, packed);
         }
         *reinterpret_cast<uint32_t*>(smem + lrow * SROW + lcol0) = packed;
       }
@@ -464,7 +509,7 @@ inline int cap_grid(int64_t items, int threads, int max_blocks = 256 * 16) {
   return (int)(b > max_blocks ? max_blocks : b);
 }
 
-template <int AMODE, int WM, int WN, int TM, int TN, bool BIAS, bool ACC>
+template <int AMODE, int WM, int WN, int TM, int TN, bool BIAS, bool ACC, int VAR = 0>
 int launch_cfg(i8ie_ctx* ctx, const IgemmArgs& a, const char* name, int kbytes, double ops, double bytes) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -472,25 +517,40 @@ int launch_cfg(i8ie_ctx* ctx, const IgemmArgs& a, const char* name, int kbytes, 
   char tag[64];
   snprintf(tag, sizeof(tag), "%s|M%d,N%d,K%d", name, a.M, a.N, kbytes);
   I8ieProfScope prof(ctx, ctx->prof ? tag : name, ops, bytes);
-  igemm_u8s8_kernel<AMODE, WM, WN, TM, TN, BIAS, ACC>
+  igemm_u8s8_kernel<AMODE, WM, WN, TM, TN, BIAS, ACC, VAR>
       <<<tiles_m * tiles_n, WM * WN * 64, 0, ctx->stream>>>(a, tiles_m, tiles_n, m_fastest);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }
 
+template <int AMODE, bool BIAS, bool ACC, int VAR>
+int launch_tile_var(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, double bytes) {
+  if (a.N <= 32)
+    return launch_cfg<AMODE, 4, 1, 1, 1, BIAS, ACC, VAR>(ctx, a, AMODE ? "igemm_conv_128x32" : "igemm_lin_128x32", kbytes,
+                                                         ops, bytes);
+  if (a.N <= 64)
+    return launch_cfg<AMODE, 2, 2, 2, 1, BIAS, ACC, VAR>(ctx, a, AMODE ? "igemm_conv_128x64" : "igemm_lin_128x64", kbytes,
+                                                         ops, bytes);
+  if (a.N <= 96)
+    return launch_cfg<AMODE, 4, 1, 1, 3, BIAS, ACC, VAR>(ctx, a, AMODE ? "igemm_conv_128x96" : "igemm_lin_128x96", kbytes,
+                                                         ops, bytes);
+  return launch_cfg<AMODE, 2, 2, 2, 2, BIAS, ACC, VAR>(ctx, a, AMODE ? "igemm_conv_128x128" : "igemm_lin_128x128", kbytes,
+                                                       ops, bytes);
+}
+
+// Default: one LDS stage (VAR 3).  Measured on MI355X (tools/bench_layer.py, AlexNet conv2-5): half the
+// LDS lets a third wave per SIMD in, +10 % over the two-stage form; loads two tiles ahead and
+// s_setprio around the MFMAs measured within 2 % of the baseline.  ctx->variant selects the others.
 template <int AMODE, bool BIAS, bool ACC>
 int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, double bytes) {
-  if (a.N <= 32)
-    return launch_cfg<AMODE, 4, 1, 1, 1, BIAS, ACC>(ctx, a, AMODE ? "igemm_conv_128x32" : "igemm_lin_128x32", kbytes,
-                                                    ops, bytes);
-  if (a.N <= 64)
-    return launch_cfg<AMODE, 2, 2, 2, 1, BIAS, ACC>(ctx, a, AMODE ? "igemm_conv_128x64" : "igemm_lin_128x64", kbytes,
-                                                    ops, bytes);
-  if (a.N <= 96)
-    return launch_cfg<AMODE, 4, 1, 1, 3, BIAS, ACC>(ctx, a, AMODE ? "igemm_conv_128x96" : "igemm_lin_128x96", kbytes,
-                                                    ops, bytes);
-  return launch_cfg<AMODE, 2, 2, 2, 2, BIAS, ACC>(ctx, a, AMODE ? "igemm_conv_128x128" : "igemm_lin_128x128", kbytes,
-                                                  ops, bytes);
+  if (AMODE == 1 && !BIAS && !ACC) {
+    if (ctx->variant == 10) return launch_tile_var<1, false, false, 0>(ctx, a, kbytes, ops, bytes);
+    if (ctx->variant == 6 && a.N <= 96 && a.N > 64)  // 256 x 96 tile, 4 waves of 64 x 96
+      return launch_cfg<1, 4, 1, 2, 3, false, false, 3>(ctx, a, "igemm_conv_256x96", kbytes, ops, bytes);
+    if (ctx->variant == 4 && a.N % 256 == 0)  // 256 x 256 tile, 8 waves, two stages
+      return launch_cfg<1, 2, 4, 4, 2, false, false, 0>(ctx, a, "igemm_conv_256x256", kbytes, ops, bytes);
+  }
+  return launch_tile_var<AMODE, BIAS, ACC, 3>(ctx, a, kbytes, ops, bytes);
 }
 
 }  // namespace

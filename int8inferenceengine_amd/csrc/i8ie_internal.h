@@ -17,6 +17,8 @@ struct i8ie_ctx {
   void* pool = nullptr;  // I8iePool* (i8ie_ctx.hip): stream-ordered caching allocator
   void* prof = nullptr;  // I8ieProf* (i8ie_ctx.hip): HIP-event timing of every launch, when enabled
   unsigned options = 0;  // bit 0: I8IE_OPT_FORCE_FALLBACK
+  int variant = 0;  // I8IE_OPT_KERNEL_VARIANT: selects among compiled kernel variants (A/B timing aid)
+  int prof_mfma_only = 0;  // time only the contraction kernels (fewer event packets in a timed region)
 };
 
 // Per-launch HIP-event timing on the ctx's stream (off unless i8ie_profile_start was
@@ -26,11 +28,13 @@ void i8ie_prof_end(i8ie_ctx* ctx);
 struct I8ieProfScope {
   i8ie_ctx* c;
   I8ieProfScope(i8ie_ctx* ctx, const char* name, double ops, double bytes) : c(ctx) {
-    if (c->prof) i8ie_prof_begin(c, name, ops, bytes);
+    on = c->prof != nullptr && (!c->prof_mfma_only || ops > 0.0);
+    if (on) i8ie_prof_begin(c, name, ops, bytes);
   }
   ~I8ieProfScope() {
-    if (c->prof) i8ie_prof_end(c);
+    if (on) i8ie_prof_end(c);
   }
+  bool on;
 };
 
 void i8ie_set_error(const char* fmt, ...);

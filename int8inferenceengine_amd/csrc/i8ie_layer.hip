@@ -195,7 +195,11 @@ extern "C" {
 
 int i8ie_ctx_set_option(i8ie_ctx* ctx, int option, int value) {
   I8IE_REQUIRE(ctx != nullptr, "null ctx");
-  I8IE_REQUIRE(option == I8IE_OPT_FORCE_FALLBACK, "unknown option");
+  I8IE_REQUIRE(option == I8IE_OPT_FORCE_FALLBACK || option == I8IE_OPT_KERNEL_VARIANT, "unknown option");
+  if (option == I8IE_OPT_KERNEL_VARIANT) {
+    ctx->variant = value;
+    return I8IE_OK;
+  }
   if (value)
     ctx->options |= 1;
   else
@@ -336,8 +340,10 @@ static int layer_create(i8ie_ctx* ctx, bool conv, const int8_t* qw_host, const i
     if ((rc = i8ie_malloc(ctx, (size_t)L->Npad * L->Kpad, (void**)&L->Bpack)) != I8IE_OK) break;
     if ((rc = i8ie_malloc(ctx, (size_t)n * 4, (void**)&L->wsum)) != I8IE_OK) break;
     if ((rc = i8ie_malloc(ctx, (size_t)n * 4, (void**)&L->oc)) != I8IE_OK) break;
-    if ((rc = i8ie_malloc(ctx, (size_t)n * 4, (void**)&L->ocp)) != I8IE_OK) break;
-    if ((rc = i8ie_malloc(ctx, (size_t)n * 4, (void**)&L->biasf)) != I8IE_OK) break;
+    if ((rc = i8ie_malloc(ctx, (size_t)L->Npad * 4, (void**)&L->ocp)) != I8IE_OK) break;  // padded: vector loads
+    if ((rc = i8ie_malloc(ctx, (size_t)L->Npad * 4, (void**)&L->biasf)) != I8IE_OK) break;
+    if ((rc = i8ie_memset(ctx, L->ocp, 0, (size_t)L->Npad * 4)) != I8IE_OK) break;
+    if ((rc = i8ie_memset(ctx, L->biasf, 0, (size_t)L->Npad * 4)) != I8IE_OK) break;
     if ((rc = i8ie_memcpy_h2d(ctx, L->qw, qw_host, (size_t)n * K)) != I8IE_OK) break;
     if ((rc = i8ie_memcpy_h2d(ctx, L->qb, qb_host, (size_t)n)) != I8IE_OK) break;
     if ((rc = i8ie_launch_pad_rows(ctx, L->qw, n, K, L->Bpack, L->Npad, L->Kpad, 0)) != I8IE_OK) break;

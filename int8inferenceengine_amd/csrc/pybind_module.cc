@@ -755,7 +755,8 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
   });
   m.def("trim", []() { check(i8ie_trim(ctx())); });
   m.def("force_fallback", [](bool on) { check(i8ie_ctx_set_option(ctx(), I8IE_OPT_FORCE_FALLBACK, on ? 1 : 0)); });
-  m.def("profile_start", []() { check(i8ie_profile_start(ctx())); });
+  m.def("profile_start", [](bool mfma_only) { check(i8ie_profile_start(ctx(), mfma_only ? 1 : 0)); },
+        py::arg("mfma_only") = false);
   m.def("profile_stop", []() {
     std::vector<i8ie_profile_entry> e(64);
     int n = 0;

@@ -1,0 +1,116 @@
+// Measured ceilings for the int8 MFMA path on this device (tuning aid, not part of the product):
+//   mode 0: register-only v_mfma_i32_32x32x32_i8, 4 independent accumulators per wave
+//   mode 1: same MFMAs, each k-step's 4 fragments (2 A + 2 B, 16 B per lane each) re-read from LDS
+//           (the 64x64-per-wave tiling of the igemm kernel: 1 KiB of ds_read_b128 per MFMA)
+//   mode 2: mode 1 + per "tile" 8 ds_write_b128 and one barrier (the staging traffic)
+//   mode 3: as 2, but the 8 writes are spread over the 4 k-steps (2 after each MFMA group)
+//   mode 4: as 3, writes placed before each MFMA group
+//   mode 5: barrier only, no writes (what LDS-DMA staging could approach)
+//   mode 6: as 3 with fragment double-buffering (next k-step's reads issued before the MFMAs)
+// build: hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(int iters, int* out) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 256 * 144];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  v16i acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = r + tid;
+  v4i a[2] = {{tid, 1, 2, 3}, {tid + 1, 5, 6, 7}}, b[2] = {{9, tid, 2, 3}, {tid + 4, 5, 1, 7}};
+  for (int i = tid; i < 2 * 256 * 144 / 4; i += 256) reinterpret_cast<int*>(smem)[i] = i * 2654435761u;
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1;
+  int ard[2], brd[2];
+  for (int m = 0; m < 2; ++m) ard[m] = ((wm * 2 + m) * 32 + (lane & 31)) * 144 + (lane >> 5) * 16;
+  for (int n = 0; n < 2; ++n) brd[n] = 128 * 144 + ((wn * 2 + n) * 32 + (lane & 31)) * 144 + (lane >> 5) * 16;
+  const int wr = (tid >> 3) * 144 + (tid & 7) * 16;
+  v4i st[8];
+  for (int i = 0; i < 8; ++i) st[i] = v4i{tid + i, i, 3, 4};
+  v4i a2[2], b2[2];
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 6) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const v4i*>(smem + ard[m]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const v4i*>(smem + brd[n]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (MODE >= 1 && MODE != 6) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const v4i*>(smem + ks * 32 + ard[m]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) b[n] = *reinterpret_cast<const v4i*>(smem + ks * 32 + brd[n]);
+      }
+      if (MODE == 6 && ks < 3) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) a2[m] = *reinterpret_cast<const v4i*>(smem + (ks + 1) * 32 + ard[m]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) b2[n] = *reinterpret_cast<const v4i*>(smem + (ks + 1) * 32 + brd[n]);
+      }
+      if (MODE == 4) {
+        *reinterpret_cast<v4i*>(smem + 256 * 144 + wr + (2 * ks) * 32 * 144) = st[2 * ks] ^ (int)0x80808080;
+        *reinterpret_cast<v4i*>(smem + 256 * 144 + wr + (2 * ks + 1) * 32 * 144) = st[2 * ks + 1];
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[n], a[m], acc[m][n], 0, 0, 0);
+      if (MODE == 3 || MODE == 6) {
+        *reinterpret_cast<v4i*>(smem + 256 * 144 + wr + (2 * ks) * 32 * 144) = st[2 * ks] ^ (int)0x80808080;
+        *reinterpret_cast<v4i*>(smem + 256 * 144 + wr + (2 * ks + 1) * 32 * 144) = st[2 * ks + 1];
+      }
+      if (MODE == 6 && ks < 3) {
+        a[0] = a2[0]; a[1] = a2[1]; b[0] = b2[0]; b[1] = b2[1];
+      }
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<v4i*>(smem + 256 * 144 + wr + i * 32 * 144) = st[i] ^ (int)0x80808080;
+    }
+    if (MODE >= 2) __syncthreads();
+    if (MODE >= 2) st[it & 7].x += acc[0][0][0];
+  }
+  int s = 0;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int MODE>
+void run(const char* name, int blocks_per_cu) {
+  int* out;
+  const int blocks = 256 * blocks_per_cu, iters = 2000;
+  hipMalloc(&out, blocks * 256 * 4);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  k<MODE><<<blocks, 256>>>(200, out);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k<MODE><<<blocks, 256>>>(iters, out);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double ops = (double)blocks * 4 * iters * 16 * 65536.0;
+  printf("%-28s blocks/CU %d: %.3f ms  %.0f TOPS\n", name, blocks_per_cu, ms, ops / (ms * 1e-3) / 1e12);
+  hipFree(out);
+}
+
+int main() {
+  for (int b = 1; b <= 2; ++b) {
+    run<0>("mfma only", b);
+    run<1>("mfma + lds frag reads", b);
+    run<2>("mfma + reads + writes + bar", b);
+    run<3>("writes spread after mfma", b);
+    run<4>("writes spread before mfma", b);
+    run<5>("reads + barrier, no writes", b);
+    run<6>("spread writes + frag dbuf", b);
+  }
+  return 0;
+}
