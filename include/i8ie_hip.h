@@ -193,6 +193,16 @@ int i8ie_layer_forward_fused(i8ie_layer* layer, const uint8_t* in_dev, int in_la
                              int h, int w, float s_in, uint8_t zp_in, int relu, uint8_t* out_dev,
                              int out_layout, int out_border, int32_t* acc_dbg_dev);
 int i8ie_layer_preferred_layout(const i8ie_layer* layer, int* layout);
+/* First layer fused with the input quantisation (Module.__call__ quantises the FP32 input with
+ * 0.025 / 127, i8ie/module.py:20, and hands it straight to the first Conv2d): reads FP32 NCHW,
+ * computes q = (u8)(x / q_scale + q_zp) exactly as src/quantize_utils.cc:44-52 and the conv of
+ * src/conv2d.cc:100-142 on it, writes NHWC u8 (+ optional border / relu).  Only for layers and
+ * geometries where i8ie_layer_accepts_f32_input says yes (<= 3 channels, stride % 4 == 0,
+ * out features % 32 == 0): AlexNet's 11x11 stride-4 conv1.  Identical bytes to
+ * i8ie_quantize_f32_u8 followed by i8ie_layer_forward_fused. */
+int i8ie_layer_accepts_f32_input(const i8ie_layer* layer, int h, int w, int* yes);
+int i8ie_layer_forward_f32_input(i8ie_layer* layer, const float* in_nchw_dev, int m, int h, int w, float q_scale,
+                                 uint8_t q_zp, int relu, uint8_t* out_nhwc_dev, int out_border);
 /* padding of a conv layer (0 for Linear): the input border that makes its gather predicate-free */
 int i8ie_layer_padding(const i8ie_layer* layer, int* pad);
 int i8ie_layer_destroy(i8ie_layer* layer);

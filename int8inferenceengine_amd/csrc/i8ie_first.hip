@@ -1,0 +1,361 @@
+// i8ie_first.hip -- small-C strided Conv2d (AlexNet conv1: 3 -> 96 channels, 11x11, stride 4)
+// as a weights-stationary kernel, plus the fused quantize+repack that feeds it from the FP32 input.
+//
+// conv1 is 9 % of AlexNet's MACs but was 28 % of the device time as quantize + repack + implicit
+// GEMM: with K = 363 the GEMM is bound by staging (every input byte gathered ~8 times, the 61 KB
+// weight panel re-staged for every 128 pixels) and by its epilogue.  Here instead:
+//   * quantize_repack_kernel: FP32 NCHW -> "grouped" u8 image [n][Hp][WG][16] in one pass
+//     (16 bytes = 4 pixels x (3 channels + pad byte), zero-point padded borders): the reference's
+//     quantize (x / scale + zp, truncate, low 8 bits; src/quantize_utils.cc:44-52) with a fast
+//     path that is exact by the same argument as the requantiser's, IEEE sequence as fallback;
+//   * conv_smallc_kernel: persistent blocks, one wave per 32 output features whose weight slice
+//     [32][K] lives in VGPRs for the whole kernel (no B traffic, no LDS for B); a block walks bands
+//     of RB output rows, each band's input patch is a CONTIGUOUS piece of the grouped image, copied
+//     once into LDS (re-biased ^0x80) while the previous band is being multiplied; an MFMA A
+//     fragment is one ds_read_b128 at base(pixel) + offset(tap); epilogue = the igemm requantiser,
+//     wave-private LDS transpose, 16-byte NHWC stores.
+// INT32 accumulators are the reference's sums (K order permuted, padded taps have zero weights).
+#include "i8ie_internal.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+struct FRequant {
+  float sa, sb, sc, zpf, ms;
+  int fast;
+};
+
+__device__ __forceinline__ int frequant_exact(float cf, const FRequant& q, int lo) {
+  const float deq = (cf * q.sa) * q.sb;  // src/quantize_utils.cc:30-33
+  const float v = deq / q.sc + q.zpf;
+  const int u = (v >= 255.0f) ? 255 : ((v < 0.0f) ? 0 : (int)v);
+  return u > lo ? u : lo;
+}
+// Four accumulators -> one packed dword.  See requant_pack4 in i8ie_igemm.hip for the proof that the
+// fast path equals the reference sequence; one (rare) branch per dword instead of two per element.
+__device__ __forceinline__ uint32_t frequant_pack4(int c0, int c1, int c2, int c3, const FRequant& q, int lo,
+                                                   float lof) {
+  const int c[4] = {c0, c1, c2, c3};
+  uint32_t packed = 0;
+  float worst = q.fast ? 1.0f : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float e = __builtin_fmaf((float)c[r], q.ms, q.zpf - 0.5f);
+    packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(e, lof), r, packed);
+    worst = __builtin_fminf(worst, __builtin_fabsf(__builtin_amdgcn_fractf(e) - 0.5f));
+  }
+  if (worst >= 2.44140625e-4f) return packed;
+  packed = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) packed |= (uint32_t)frequant_exact((float)c[r], q, lo) << (8 * r);
+  return packed;
+}
+
+constexpr int kMaxKS = 24;
+
+struct FirstArgs {
+  const uint8_t* img;  // grouped u8 image [n][Hp][WG][16]
+  int Hp;
+  int KH, KWG, sh, swg, OH, OW;
+  int RB, bands_per_img, total_bands;
+  int PR, WG;  // patch rows, 16-byte groups per patch row
+  const int8_t* B;  // [Npad][Kpad] K ordered (kh, group, px, ch), zero padded
+  int Kpad, N;
+  const int32_t* ocp;
+  FRequant rq;
+  int relu_lo;
+  uint8_t* out;  // NHWC [n][OH + 2ob][OW + 2ob][N]
+  int ob;
+  int toff[2 * kMaxKS];  // LDS byte offset of K chunk q inside a pixel's window
+};
+
+// ---- fused quantize + repack: FP32 NCHW -> grouped u8 [n][Hp][WG][16] -------------------------
+// exact quantize: t = x / scale + zp (fp32 divide, fp32 add), q = ((int)t) & 0xFF.
+// Fast path: est = fma(x, fl(1/scale), zp).  For |est| < 1024, |t - est| < 2e-4 (one rounding each
+// of 1/scale and of the fma against the two roundings of the reference, all on magnitudes < 1151),
+// so when est is further than 2^-10 from an integer t truncates to the same integer.
+__device__ __forceinline__ uint32_t quant_exact(float x, float scale, float zpf, float rscale) {
+  const float est = __builtin_fmaf(x, rscale, zpf);
+  const float fr = __builtin_amdgcn_fractf(est);
+  if (__builtin_fabsf(est) < 1024.0f && __builtin_fabsf(fr - 0.5f) <= 0.5f - 9.765625e-4f)
+    return (uint32_t)((int)est) & 0xFFu;
+  const float t = x / scale + zpf;  // src/quantize_utils.cc:49
+  return (uint32_t)((int)t) & 0xFFu;
+}
+
+__global__ __launch_bounds__(256) void quantize_repack_kernel(const float* __restrict__ x, uint8_t* __restrict__ out,
+                                                              int64_t total, int c, int h, int w, int Hp, int WG,
+                                                              int pad, float scale, float zpf, float rscale,
+                                                              uint32_t zp) {
+  const int64_t gstride = (int64_t)gridDim.x * 256;
+  const size_t cs = (size_t)h * w;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += gstride) {
+    const int g = (int)(e % WG);
+    int64_t t = e / WG;
+    const int yp = (int)(t % Hp);
+    const int64_t img = t / Hp;
+    const int y = yp - pad, x0 = 4 * g - pad;
+    const bool yin = y >= 0 && y < h;
+    const int yc = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    const float* plane = x + ((size_t)img * c * h + yc) * w;
+    float v[12];
+    int xc[4];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const int xx = x0 + px;
+      xc[px] = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {  // unconditional (clamped) loads: all 12 in flight together
+      const float* row = plane + (ch < c ? ch : 0) * cs;
+#pragma unroll
+      for (int px = 0; px < 4; ++px) v[ch * 4 + px] = row[xc[px]];
+    }
+    uint32_t wds[4];
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      const int xx = x0 + px;
+      const bool in = yin && xx >= 0 && xx < w;
+      uint32_t d = zp * 0x01010101u;  // padding pixel / pad byte: the input zero point (src/conv2d.cc:24-28)
+      if (in) {
+        d = zp << 24;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) d |= (ch < c ? quant_exact(v[ch * 4 + px], scale, zpf, rscale) : zp) << (8 * ch);
+      }
+      wds[px] = d;
+    }
+    reinterpret_cast<uint4*>(out)[e] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int nthreads = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5;
+  const int patch_bytes = p.PR * p.WG * 16;
+  uint8_t* scratch = smem + 2 * patch_bytes + wave * (32 * 36);  // wave-private 32 px x 36 B
+
+  // ---- this wave's weight slice -> registers (stays for the whole kernel) ---------------------
+  v4i breg[KS];
+  {
+    const int8_t* brow = p.B + (size_t)(wave * 32 + (lane & 31)) * p.Kpad + hh * 16;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const v4i z = {0, 0, 0, 0};
+      breg[j] = (j * 32 + 32 <= p.Kpad) ? *reinterpret_cast<const v4i*>(brow + j * 32) : z;
+    }
+  }
+  int init[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) init[r] = p.ocp[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+  int koff[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) koff[j] = hh ? p.toff[2 * j + 1] : p.toff[2 * j];
+
+  const int groups = p.PR * p.WG;
+  const int fill_iters = (groups + nthreads - 1) / nthreads;
+  const FRequant rq = p.rq;
+  const int lo = p.relu_lo;
+  const float lof = (float)lo;
+  const int OHp = p.OH + 2 * p.ob, OWp = p.OW + 2 * p.ob;
+
+  auto band_origin = [&](int band, int& img, int& rb0, int& rows) {
+    img = band / p.bands_per_img;
+    rb0 = (band - img * p.bands_per_img) * p.RB;
+    rows = p.OH - rb0 < p.RB ? p.OH - rb0 : p.RB;
+  };
+  // a band's patch = PR consecutive rows of the grouped image = one contiguous run of 16-byte groups
+  auto band_src = [&](int band) -> const v4i* {
+    int img, rb0, rows;
+    band_origin(band, img, rb0, rows);
+    return reinterpret_cast<const v4i*>(p.img) + ((size_t)img * p.Hp + (size_t)rb0 * p.sh) * p.WG;
+  };
+  auto fill_sync = [&](int band, uint8_t* dst) {
+    const v4i* src = band_src(band);
+    for (int e = tid; e < groups; e += nthreads)
+      *reinterpret_cast<v4i*>(dst + e * 16) = src[e] ^ (int)0x80808080;  // u8 -> s8 re-bias
+  };
+
+  int band = blockIdx.x;
+  if (band >= p.total_bands) return;
+  int cur = 0;
+  fill_sync(band, smem);
+  __syncthreads();
+
+  for (; band < p.total_bands; band += gridDim.x) {
+    int img, rb0, rows;
+    band_origin(band, img, rb0, rows);
+    const int npix = rows * p.OW;
+    const int ntiles = (npix + 31) >> 5;
+    const int nband = band + gridDim.x;
+    const bool has_next = nband < p.total_bands;
+    const v4i* nsrc = band_src(has_next ? nband : band);
+    const uint8_t* patch = smem + cur * patch_bytes;
+    uint8_t* npatch = smem + (cur ^ 1) * patch_bytes;
+    const int iters = ntiles > fill_iters ? ntiles : fill_iters;
+    // pixel index of this lane inside the band, as (row, col): the MFMA lane map (lane & 31) and the
+    // store map (lane >> 1)
+    int pr = 0, pc = lane & 31, sr = 0, sc = lane >> 1;
+    while (pc >= p.OW) { pc -= p.OW; ++pr; }
+    while (sc >= p.OW) { sc -= p.OW; ++sr; }
+
+    for (int it = 0; it < iters; ++it) {
+      // (1) start fetching one group of the NEXT band's patch
+      const int e = tid + it * nthreads;
+      const bool do_fill = has_next && it < fill_iters && e < groups;
+      // unconditional load (index clamped): a branch here would put an s_waitcnt vmcnt(0) right behind it
+      const v4i fetched = nsrc[e < groups ? e : groups - 1];
+      // (2) one 32-pixel x 32-feature tile of the CURRENT band
+      if (it < ntiles) {
+        // (row, col) of this lane's pixel: walked incrementally, no division
+        const int r = pr < rows ? pr : rows - 1, col = pr < rows ? pc : p.OW - 1;
+        const uint8_t* abase = patch + ((r * p.sh) * p.WG + col * p.swg) * 16;
+        v16i acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = init[q];
+        // A fragments run DEPTH k-steps ahead of the MFMA chain (one ds_read_b128 each): with a
+        // single accumulator chain an LDS round trip per step would otherwise be exposed
+        constexpr int DEPTH = KS < 6 ? KS : 6;
+        v4i ring[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) ring[j] = *reinterpret_cast<const v4i*>(abase + koff[j]);
+        __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks every read next to its MFMA (1 in flight)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          const v4i af = ring[j % DEPTH];
+          if (j + DEPTH < KS) {
+            ring[j % DEPTH] = *reinterpret_cast<const v4i*>(abase + koff[j + DEPTH]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(breg[j], af, acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue: lane = pixel, regs = features (4 consecutive per group)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint32_t packed =
+              frequant_pack4(acc[g * 4 + 0], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3], rq, lo, lof);
+          *reinterpret_cast<uint32_t*>(scratch + (lane & 31) * 36 + 8 * g + 4 * hh) = packed;
+        }
+        // wave-private transpose: lane l stores 16 bytes (features 16*(l&1) .. +15) of pixel l >> 1
+        const int sp = lane >> 1, sh16 = lane & 1;
+        const int sm = it * 32 + sp;
+        if (sm < npix) {
+          const uint32_t* s = reinterpret_cast<const uint32_t*>(scratch + sp * 36 + sh16 * 16);
+          const uint4 val = make_uint4(s[0], s[1], s[2], s[3]);
+          const size_t pix = ((size_t)img * OHp + rb0 + sr + p.ob) * OWp + sc + p.ob;
+          *reinterpret_cast<uint4*>(p.out + pix * p.N + wave * 32 + sh16 * 16) = val;
+        }
+      }
+      // (3) park the fetched group in the other patch buffer
+      if (do_fill) *reinterpret_cast<v4i*>(npatch + e * 16) = fetched ^ (int)0x80808080;
+      // advance both pixel walks by 32 pixels
+      pc += 32;
+      while (pc >= p.OW) { pc -= p.OW; ++pr; }
+      sc += 32;
+      while (sc >= p.OW) { sc -= p.OW; ++sr; }
+    }
+    __syncthreads();  // everyone done with patch[cur]; patch[cur^1] complete
+    cur ^= 1;
+  }
+}
+
+template <int KS>
+int launch_first(i8ie_ctx* ctx, const FirstArgs& a, int blocks, int threads, size_t lds) {
+  I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_smallc_kernel<KS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  conv_smallc_kernel<KS><<<blocks, threads, lds, ctx->stream>>>(a);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+}  // namespace
+
+struct I8ieFirstCall {
+  const float* x;        // FP32 NCHW input (fused quantize), or nullptr when `grouped` is given
+  const uint8_t* grouped;  // grouped u8 image produced elsewhere (repack_smallc), or nullptr
+  uint8_t* scratch;      // room for the grouped image when x is given: n * Hp * WG * 16 bytes
+  int n, c, h, w;
+  float q_scale;
+  int q_zp;
+  int KH, KW, KWG, stride, pad, OH, OW;
+  const int8_t* B;
+  int Kpad, K2, N;
+  const int32_t* ocp;
+  float s_in, s_w, s_out;
+  int zp_out, relu;
+  uint8_t* out;
+  int ob;
+};
+
+int i8ie_first_supported(int c, int stride, int n_out, int K2, int KH, int KWG, int OW) {
+  if (c > 3 || stride % 4 != 0) return 0;  // 3 data channels + 1 pad byte per pixel
+  if (n_out % 32 != 0 || n_out / 32 > 8) return 0;
+  if ((K2 + 31) / 32 > kMaxKS) return 0;
+  const int WG = (OW - 1) * (stride / 4) + KWG;
+  if ((size_t)KH * WG * 16 * 2 > 60 * 1024) return 0;  // even one-row bands would not fit
+  return 1;
+}
+
+// grouped-image geometry shared with repack_smallc (i8ie_igemm.hip): Hp = (OH-1)*stride + KH rows,
+// WG = (OW-1)*stride/4 + KWG groups per row
+size_t i8ie_first_scratch_bytes(int n, int KH, int KWG, int stride, int OH, int OW) {
+  const size_t Hp = (size_t)(OH - 1) * stride + KH, WG = (size_t)(OW - 1) * (stride / 4) + KWG;
+  return (size_t)n * Hp * WG * 16;
+}
+
+int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
+  FirstArgs a{};
+  a.KH = c.KH; a.KWG = c.KWG; a.sh = c.stride; a.swg = c.stride / 4; a.OH = c.OH; a.OW = c.OW;
+  a.WG = (c.OW - 1) * a.swg + c.KWG;
+  a.Hp = (c.OH - 1) * c.stride + c.KH;
+  const uint8_t* grouped = c.grouped;
+  if (c.x != nullptr) {
+    const int64_t total = (int64_t)c.n * a.Hp * a.WG;
+    I8ieProfScope prof(ctx, "quantize_repack_f32", 0.0, 4.0 * c.n * c.c * c.h * c.w + 16.0 * total);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    quantize_repack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.x, c.scratch, total, c.c, c.h, c.w, a.Hp, a.WG, c.pad,
+                                                                 c.q_scale, (float)c.q_zp, 1.0f / c.q_scale,
+                                                                 (uint32_t)(c.q_zp & 0xFF));
+    I8IE_LAUNCH_CHECK();
+    grouped = c.scratch;
+  }
+  a.img = grouped;
+  // rows per band: as many as keep two patches within ~44 KB (3 blocks per CU)
+  int RB = 1;
+  while (RB < c.OH && (size_t)(RB * a.sh + c.KH) * a.WG * 16 * 2 <= 44 * 1024 && (RB + 1) * c.OW <= 512) ++RB;
+  a.RB = RB;
+  a.PR = (RB - 1) * a.sh + c.KH;
+  a.bands_per_img = (c.OH + RB - 1) / RB;
+  a.total_bands = a.bands_per_img * c.n;
+  a.B = c.B; a.Kpad = c.Kpad; a.N = c.N; a.ocp = c.ocp;
+  a.rq.sa = c.s_in; a.rq.sb = c.s_w; a.rq.sc = c.s_out; a.rq.zpf = (float)c.zp_out;
+  const double ms = (double)c.s_in * (double)c.s_w / (double)c.s_out;
+  a.rq.ms = (float)ms;
+  a.rq.fast = (c.s_in > 1e-30f && c.s_w > 1e-30f && c.s_out > 1e-30f && c.s_in < 1e30f && c.s_w < 1e30f &&
+               c.s_out < 1e30f && ms > 1e-30 && ms < 1e30) ? 1 : 0;
+  a.relu_lo = c.relu ? c.zp_out : 0;
+  a.out = c.out; a.ob = c.ob;
+  const int ks_needed = (c.K2 + 31) / 32;
+  const int nchunks = c.KH * c.KWG;
+  for (int q = 0; q < 2 * kMaxKS; ++q) {
+    const int kh = q / c.KWG, g = q - kh * c.KWG;
+    a.toff[q] = q < nchunks ? (kh * a.WG + g) * 16 : 0;  // chunks past K carry zero weights
+  }
+  const int waves = c.N / 32, threads = waves * 64;
+  const size_t lds = (size_t)2 * a.PR * a.WG * 16 + (size_t)waves * 32 * 36;
+  int blocks = 256 * 2;
+  if (blocks > a.total_bands) blocks = a.total_bands;
+  const double ops = 2.0 * c.n * c.OH * c.OW * (double)c.N * c.c * c.KH * c.KW;
+  const double bytes = 16.0 * c.n * a.Hp * a.WG + (double)c.n * c.OH * c.OW * c.N;
+  I8ieProfScope prof(ctx, "conv_smallc_wstat", ops, bytes);
+  if (ks_needed <= 6) return launch_first<6>(ctx, a, blocks, threads, lds);
+  if (ks_needed <= 10) return launch_first<10>(ctx, a, blocks, threads, lds);
+  if (ks_needed <= 17) return launch_first<17>(ctx, a, blocks, threads, lds);
+  return launch_first<kMaxKS>(ctx, a, blocks, threads, lds);
+}

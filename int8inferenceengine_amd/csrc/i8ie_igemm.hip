@@ -58,16 +58,22 @@ __device__ __forceinline__ int requant_exact(float cf, const Requant& q, int lo)
 // both sides clamp, with the same margin.  Anything closer to a half-integer replays the exact
 // sequence.  relu (max with zp_out) commutes with the monotone rounding: rne(max(e, lo)) for the
 // integer lo.
-__device__ __forceinline__ uint32_t requant_pack(int c, const Requant& q, int lo, float lof, int r, uint32_t packed) {
-  const float cf = (float)c;
-  if (q.fast) {
-    const float e = __builtin_fmaf(cf, q.ms, q.zpf - 0.5f);
-    const float fr = __builtin_amdgcn_fractf(e);
+__device__ __forceinline__ uint32_t requant_pack4(const int (&c)[4], const Requant& q, int lo, float lof) {
+  // branch-free fast path for the four bytes of one dword; `worst` = smallest distance of any of the
+  // four estimates to a rounding boundary (0 when the fast path is disabled); one rare branch per dword
+  uint32_t packed = 0;
+  float worst = q.fast ? 1.0f : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float e = __builtin_fmaf((float)c[r], q.ms, q.zpf - 0.5f);
     packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(e, lof), r, packed);
-    if (__builtin_fabsf(fr - 0.5f) >= 2.44140625e-4f) return packed;
+    worst = __builtin_fminf(worst, __builtin_fabsf(__builtin_amdgcn_fractf(e) - 0.5f));
   }
-  const uint32_t u = (uint32_t)requant_exact(cf, q, lo);
-  return (packed & ~(0xFFu << (8 * r))) | (u << (8 * r));
+  if (worst >= 2.44140625e-4f) return packed;
+  packed = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) packed |= (uint32_t)requant_exact((float)c[r], q, lo) << (8 * r);
+  return packed;
 }
 
 struct IgemmArgs {
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
         const int lrow = (wm * TM + mi) * 32 + (lane & 31);
-        uint32_t packed = 0;
+        int cv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int c = acc[mi][ni][g * 4 + r];
@@ -325,8 +331,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
             if (grow < p.M && gcol < p.N) p.acc[(size_t)grow * p.N + gcol] = c;
           }
           if (BIAS) c = (int)((float)c + (r == 0 ? bfv.x : r == 1 ? bfv.y : r == 2 ? bfv.z : bfv.w));  // src/fully_connected.cc:44
-          packed = requant_pack(c, rq, lo, lof, r, packed);
+          cv[r] = c;
         }
+        const uint32_t packed = requant_pack4(cv, rq, lo, lof);
         *reinterpret_cast<uint32_t*>(smem + lrow * SROW + lcol0) = packed;
       }
     }

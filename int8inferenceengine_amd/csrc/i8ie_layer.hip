@@ -55,6 +55,26 @@ struct I8ieIgemmCall {
 };
 int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 
+struct I8ieFirstCall {
+  const float* x;
+  const uint8_t* grouped;
+  uint8_t* scratch;
+  int n, c, h, w;
+  float q_scale;
+  int q_zp;
+  int KH, KW, KWG, stride, pad, OH, OW;
+  const int8_t* B;
+  int Kpad, K2, N;
+  const int32_t* ocp;
+  float s_in, s_w, s_out;
+  int zp_out, relu;
+  uint8_t* out;
+  int ob;
+};
+int i8ie_first_supported(int c, int stride, int n_out, int K2, int KH, int KWG, int OW);
+int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c);
+size_t i8ie_first_scratch_bytes(int n, int KH, int KWG, int stride, int OH, int OW);
+
 namespace {
 
 constexpr size_t kColBudget = (size_t)192 << 20;  // im2col scratch per chunk (fallback path F)
@@ -525,6 +545,22 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
     }
     uint8_t* rep = ws + t_bytes;
     I8IE_TRY(i8ie_launch_repack_smallc(ctx, src, rep, m, cg.c, cg.h, cg.w, Hp, Wg, cg.pad, cg.pad, zp_in));
+    if (acc == nullptr && i8ie_first_supported(cg.c, cg.stride, L->n, L->K2, cg.kh, L->kwg, cg.ow)) {
+      // weights-stationary small-C kernel (i8ie_first.hip) on the grouped image
+      uint8_t* dst = o_bytes ? ws + t_bytes + r_bytes : out;
+      const int ob = o_bytes ? 0 : out_border;
+      if (!o_bytes && out_border > 0) I8IE_HIP_TRY(hipMemsetAsync(out, L->zp_out, out_phys, ctx->stream));
+      I8ieFirstCall f{};
+      f.x = nullptr; f.grouped = rep; f.scratch = nullptr;
+      f.n = m; f.c = cg.c; f.h = cg.h; f.w = cg.w; f.q_scale = s_in; f.q_zp = zp_in;
+      f.KH = cg.kh; f.KW = cg.kw; f.KWG = L->kwg; f.stride = cg.stride; f.pad = cg.pad; f.OH = cg.oh; f.OW = cg.ow;
+      f.B = L->Bpack2; f.Kpad = L->Kpad2; f.K2 = L->K2; f.N = L->n; f.ocp = L->ocp;
+      f.s_in = s_in; f.s_w = L->s_w; f.s_out = L->s_out; f.zp_out = L->zp_out; f.relu = relu;
+      f.out = dst; f.ob = ob;
+      I8IE_TRY(i8ie_first_launch(ctx, f));
+      if (o_bytes) I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, dst, out, m, cg.kc, cg.oh, cg.ow, 0));
+      return I8IE_OK;
+    }
     c.A = rep;
     c.a_bytes = (size_t)m * Hp * Wg * 16;
     c.Hp = Hp; c.Wp = Wg; c.C = 16; c.KH = cg.kh; c.KW = L->kwg;
@@ -536,6 +572,46 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
   I8IE_TRY(i8ie_igemm_launch(ctx, c));
   if (o_bytes) I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, c.out, out, m, cg.kc, cg.oh, cg.ow, 0));
   return I8IE_OK;
+}
+
+int i8ie_layer_accepts_f32_input(const i8ie_layer* L, int h, int w, int* yes) {
+  I8IE_REQUIRE(L && yes, "null argument");
+  *yes = 0;
+  if (!L->conv || L->path != PATH_B || force_fallback(L->ctx)) return I8IE_OK;
+  ConvGeom cg;
+  if (conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg) != I8IE_OK) return I8IE_OK;
+  *yes = i8ie_first_supported(L->c, L->stride, L->n, L->K2, L->kh, L->kwg, cg.ow);
+  return I8IE_OK;
+}
+
+int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, int w, float q_scale, uint8_t q_zp,
+                                 int relu, uint8_t* out, int out_border) {
+  I8IE_REQUIRE(L && in && out, "null argument");
+  I8IE_REQUIRE(m > 0 && out_border >= 0, "bad argument");
+  int yes = 0;
+  I8IE_TRY(i8ie_layer_accepts_f32_input(L, h, w, &yes));
+  if (!yes) {
+    i8ie_set_error("i8ie_layer_forward_f32_input: layer/geometry not supported by the fused first-layer kernel");
+    return I8IE_ERR_STATE;
+  }
+  i8ie_ctx* ctx = L->ctx;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8IE_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15u) == 0, "output must be 16-byte aligned");
+  I8IE_TRY(ensure_offsets(L, q_scale, q_zp));
+  ConvGeom cg;
+  I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
+  if (out_border > 0)
+    I8IE_HIP_TRY(hipMemsetAsync(out, L->zp_out,
+                                (size_t)m * cg.kc * (cg.oh + 2 * out_border) * (cg.ow + 2 * out_border), ctx->stream));
+  I8IE_TRY(i8ie_ws_reserve(ctx, i8ie_first_scratch_bytes(m, cg.kh, L->kwg, cg.stride, cg.oh, cg.ow) + 256));
+  I8ieFirstCall c{};
+  c.x = in; c.grouped = nullptr; c.scratch = (uint8_t*)ctx->ws;
+  c.n = m; c.c = cg.c; c.h = h; c.w = w; c.q_scale = q_scale; c.q_zp = q_zp;
+  c.KH = cg.kh; c.KW = cg.kw; c.KWG = L->kwg; c.stride = cg.stride; c.pad = cg.pad; c.OH = cg.oh; c.OW = cg.ow;
+  c.B = L->Bpack2; c.Kpad = L->Kpad2; c.K2 = L->K2; c.N = L->n; c.ocp = L->ocp;
+  c.s_in = q_scale; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
+  c.out = out; c.ob = out_border;
+  return i8ie_first_launch(ctx, c);
 }
 
 int i8ie_layer_forward(i8ie_layer* L, const uint8_t* in, int m, int h, int w, float s_in, uint8_t zp_in, uint8_t* out,

@@ -147,11 +147,16 @@ struct Tensor {
   // arguments: fuse relu; physical border wanted by the consumer (honoured for NHWC results)
   std::shared_ptr<std::function<std::shared_ptr<Storage>(bool, int)>> pend;
   bool pend_relu = false;
+  // set while this tensor is a not-yet-launched quantize(x, scale, zp): lets the first conv read x directly
+  std::shared_ptr<Storage> qsrc;
+  float qscale = 0;
+  u8_t qzp = 0;
 
   void realize(int border = 0) {
     if (!pend) return;
     st = (*pend)(pend_relu, border);
     pend.reset();
+    qsrc.reset();
   }
 
   Tensor() = default;
@@ -251,10 +256,25 @@ void bind_tensor(py::module_& m, const char* name) {
 
 // ------------------------------------------------------------ elementwise ----
 Tensor<u8_t> quantize(Tensor<float>& in, float scale, u8_t zp) {  // src/quantize_utils.cc:44-52
-  Tensor<u8_t> out(in.shape);
+  Tensor<u8_t> out;
+  out.shape = in.shape;
+  out.size = in.size;
   out.scale = scale;
   out.zero_point = zp;
-  check(i8ie_quantize_f32_u8(ctx(), in.dptr(), out.dptr(), in.size, scale, zp));
+  (void)in.dptr();  // make sure the FP32 source is on the device
+  std::shared_ptr<Storage> src = in.st;
+  const ssize_t n = in.size;
+  out.qsrc = src;
+  out.qscale = scale;
+  out.qzp = zp;
+  // deferred: a first conv layer that accepts FP32 input consumes `src` directly (fused quantize)
+  out.pend = std::make_shared<std::function<std::shared_ptr<Storage>(bool, int)>>(
+      [src, n, scale, zp](bool relu, int) {
+        auto st = device_storage((size_t)n);
+        check(i8ie_quantize_f32_u8(ctx(), (const float*)src->device_ptr(), (uint8_t*)st->dev, n, scale, zp));
+        if (relu) check(i8ie_relu_u8(ctx(), (const uint8_t*)st->dev, (uint8_t*)st->dev, n, zp));
+        return st;
+      });
   return out;
 }
 Tensor<float> dequantize(Tensor<u8_t>& in) {  // src/quantize_utils.cc:54-58
@@ -272,7 +292,7 @@ Tensor<u8_t> relu_u8(Tensor<u8_t>& in) {  // src/functional.cc:15-26
     out.scale = in.scale;
     out.zero_point = in.zero_point;
     out.pend = in.pend;
-    out.pend_relu = true;
+    out.pend_relu = true;  // (qsrc is not carried over: relu(quantize(x)) is not a plain quantize)
     return out;
   }
   const uint8_t* src = in.dptr_any();
@@ -497,6 +517,19 @@ class BaseLayer {
           if (spatial) {
             check(i8ie_layer_preferred_layout(handle.get(), &out_layout));
             check(i8ie_layer_padding(handle.get(), &pad));
+          }
+          if (spatial && out_layout == I8IE_LAYOUT_NHWC && src.pend && src.qsrc && !src.pend_relu) {
+            int yes = 0;
+            check(i8ie_layer_accepts_f32_input(handle.get(), h, w, &yes));
+            if (yes) {  // quantize + conv (+ relu) in one kernel, reading the FP32 input
+              const size_t phys = (size_t)oshp[0] * oshp[1] * (oshp[2] + 2 * border) * (oshp[3] + 2 * border);
+              auto st = device_storage(phys);
+              check(i8ie_layer_forward_f32_input(handle.get(), (const float*)src.qsrc->device_ptr(), m, h, w,
+                                                 src.qscale, src.qzp, relu ? 1 : 0, (uint8_t*)st->dev, border));
+              st->set_nhwc(oshp, border);
+              src = Tensor<u8_t>();
+              return st;
+            }
           }
           const uint8_t* ip;
           if (spatial) {

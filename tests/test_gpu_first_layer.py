@@ -1,0 +1,85 @@
+"""Fused first layer (quantize + small-C strided conv, FP32 NCHW in, NHWC u8 out) through the
+C-ABI entry i8ie_layer_forward_f32_input, against oracle quantize -> conv2d (-> relu)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import abi
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    c = abi.Ctx(0)
+    yield c
+    c.close()
+
+
+def run_first(gpu, x, qw, qb, stride, pad, q_scale, q_zp, s_w, s_out, zp_out, relu, ob):
+    lib = abi.lib()
+    n, c, h, w = x.shape
+    kc, _, kh, kw = qw.shape
+    oh, ow = (h - kh + 2 * pad) // stride + 1, (w - kw + 2 * pad) // stride + 1
+    L = C.c_void_p()
+    abi.ck(lib.i8ie_conv2d_create(gpu.h, qw.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p), kc, c, kh, kw,
+                                  stride, pad, C.c_float(s_w), C.byref(L)))
+    abi.ck(lib.i8ie_layer_set_output_qparams(L, C.c_float(s_out), C.c_uint8(zp_out)))
+    yes = C.c_int(-1)
+    abi.ck(lib.i8ie_layer_accepts_f32_input(L, h, w, C.byref(yes)))
+    if not yes.value:
+        lib.i8ie_layer_destroy(L)
+        return None
+    dx = gpu.put(np.ascontiguousarray(x, np.float32))
+    out = gpu.empty((n, oh + 2 * ob, ow + 2 * ob, kc), np.uint8)
+    abi.ck(lib.i8ie_layer_forward_f32_input(L, dx.ptr, n, h, w, C.c_float(q_scale), C.c_uint8(q_zp), 1 if relu else 0,
+                                            out.ptr, ob))
+    phys = out.get()
+    lib.i8ie_layer_destroy(L)
+    dx.free()
+    out.free()
+    if ob:
+        ring = phys.copy()
+        ring[:, ob:-ob, ob:-ob, :] = zp_out
+        assert (ring == zp_out).all()
+        phys = phys[:, ob:-ob, ob:-ob, :]
+    return np.ascontiguousarray(phys.transpose(0, 3, 1, 2))
+
+
+GEOMS = [
+    # n, c, h, w, kc, k, stride, pad
+    (2, 3, 224, 224, 96, 11, 4, 2),   # AlexNet conv1
+    (5, 3, 224, 224, 96, 11, 4, 2),   # more bands than one block walks at once
+    (3, 3, 67, 83, 64, 7, 4, 3),      # non-square, ragged last band
+    (4, 1, 40, 40, 32, 5, 4, 0),      # one channel, no padding
+    (2, 2, 50, 31, 96, 3, 8, 1),      # stride 8, two channels
+    (3, 3, 35, 35, 160, 11, 4, 5),    # 5 feature tiles, big padding
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_fused_first_layer_bit_exact(gpu, orc, geom):
+    n, c, h, w, kc, k, stride, pad = geom
+    rng = np.random.default_rng(sum(geom))
+    x = rng.uniform(-2.2, 2.6, (n, c, h, w)).astype(np.float32)
+    x.flat[::97] = rng.uniform(-9, 9, x.flat[::97].shape)  # some values outside the no-wrap window (unclamped cast)
+    q_scale, q_zp = np.float32(0.025), 127
+    q_in = orc.quantize(x, q_scale, q_zp)
+    cs = synth.conv_case(orc, 5 + sum(geom), n, c, h, w, kc, k, stride, pad, s_in=q_scale, zp_in=q_zp)
+    want, _ = orc.conv2d(q_in, cs["qw"], cs["qb"], stride, pad, q_scale, q_zp, cs["s_w"], cs["s_out"], cs["zp_out"])
+    for relu, ob in ((False, 0), (True, 2)):
+        got = run_first(gpu, x, cs["qw"], cs["qb"], stride, pad, q_scale, q_zp, cs["s_w"], cs["s_out"], cs["zp_out"],
+                        relu, ob)
+        assert got is not None, "geometry should be supported"
+        assert np.array_equal(got, orc.relu(want, cs["zp_out"]) if relu else want)
+
+
+def test_unsupported_geometries_say_no(gpu, orc):
+    for geom in [(1, 3, 32, 32, 20, 5, 1, 0), (1, 16, 13, 13, 32, 3, 4, 1), (1, 3, 64, 64, 48, 5, 4, 2)]:
+        n, c, h, w, kc, k, stride, pad = geom
+        cs = synth.conv_case(orc, 1, n, c, h, w, kc, k, stride, pad)
+        x = np.zeros((n, c, h, w), np.float32)
+        assert run_first(gpu, x, cs["qw"], cs["qb"], stride, pad, 0.025, 127, cs["s_w"], cs["s_out"], cs["zp_out"],
+                         False, 0) is None
