@@ -349,7 +349,7 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
   }
   const int waves = c.N / 32, threads = waves * 64;
   const size_t lds = (size_t)2 * a.PR * a.WG * 16 + (size_t)waves * 32 * 36;
-  int blocks = 256 * 2;
+  int blocks = 256 * 2;  // resident blocks per CU (measured: 2 beats 3 and 4 on AlexNet conv1)
   if (blocks > a.total_bands) blocks = a.total_bands;
   const double ops = 2.0 * c.n * c.OH * c.OW * (double)c.N * c.c * c.KH * c.KW;
   const double bytes = 16.0 * c.n * a.Hp * a.WG + (double)c.n * c.OH * c.OW * c.N;

@@ -466,6 +466,34 @@ __global__ __launch_bounds__(256) void reborder_u8_kernel(const uint8_t* __restr
   }
 }
 
+// fill only the border pixels of a bordered NHWC tensor [n][h+2b][w+2b][c] with the zero point
+__global__ __launch_bounds__(256) void fill_border_kernel(uint8_t* __restrict__ out, int64_t total, int h, int w,
+                                                          int c16, int b, uint32_t zp4) {
+  const int Hp = h + 2 * b, Wp = w + 2 * b;
+  const int top = b * Wp, sides = h * 2 * b, nb = 2 * top + sides;
+  const int64_t gstride = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += gstride) {
+    const int cc = (int)(e % c16);
+    int64_t t = e / c16;
+    const int bp = (int)(t % nb);
+    const int64_t img = t / nb;
+    int yp, xp;
+    if (bp < top) {
+      yp = bp / Wp;
+      xp = bp - yp * Wp;
+    } else if (bp < top + sides) {
+      const int r = (bp - top) / (2 * b), s = (bp - top) - r * (2 * b);
+      yp = b + r;
+      xp = s < b ? s : w + s;
+    } else {
+      const int q = bp - top - sides;
+      yp = b + h + q / Wp;
+      xp = q % Wp;
+    }
+    reinterpret_cast<uint4*>(out)[((img * Hp + yp) * Wp + xp) * c16 + cc] = make_uint4(zp4, zp4, zp4, zp4);
+  }
+}
+
 // ---- small-C repack: NCHW u8 [n][c<=4][h][w] -> physically padded "grouped" NHWC -----------------
 // out [n][Hp][Wg][16]: pixel (y, x) of the padded image (pad rows/cols hold the zero point;
 // x = 4*g + px) stores its channels at bytes 4*px .. 4*px+3 of group g (channels >= c hold zp;
@@ -663,6 +691,22 @@ int i8ie_launch_reborder(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, 
   const int64_t total = (int64_t)n * (h + 2 * ob) * (w + 2 * ob) * (c / 16);
   I8ieProfScope prof(ctx, "reborder_u8_nhwc", 0.0, (double)n * c * h * w + 16.0 * total);
   reborder_u8_kernel<<<cap_grid(total, 256), 256, 0, ctx->stream>>>(in, out, total, h, w, c / 16, ib, ob,
+                                                                    (uint32_t)(zp & 0xFF) * 0x01010101u);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+// border of a bordered NHWC u8 tensor := zp (c % 16 == 0; otherwise the caller memsets the whole buffer)
+int i8ie_launch_fill_border(i8ie_ctx* ctx, uint8_t* out, int n, int c, int h, int w, int b, int zp) {
+  if (b <= 0) return I8IE_OK;
+  if (c % 16 != 0 || (reinterpret_cast<uintptr_t>(out) & 15u) != 0) {
+    I8IE_HIP_TRY(hipMemsetAsync(out, zp & 0xFF, (size_t)n * (h + 2 * b) * (w + 2 * b) * c, ctx->stream));
+    return I8IE_OK;
+  }
+  const int nb = 2 * b * (w + 2 * b) + h * 2 * b;
+  const int64_t total = (int64_t)n * nb * (c / 16);
+  I8ieProfScope prof(ctx, "fill_border_u8", 0.0, 16.0 * total);
+  fill_border_kernel<<<cap_grid(total, 256), 256, 0, ctx->stream>>>(out, total, h, w, c / 16, b,
                                                                     (uint32_t)(zp & 0xFF) * 0x01010101u);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;

@@ -32,6 +32,7 @@ int i8ie_launch_reborder(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, 
                          int zp);
 int i8ie_launch_repack_smallc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int Hp,
                               int Wg, int ph, int pw, int zp);
+int i8ie_launch_fill_border(i8ie_ctx* ctx, uint8_t* out, int n, int c, int h, int w, int b, int zp);
 int i8ie_launch_maxpool_nhwc(i8ie_ctx* ctx, const uint8_t* in, int ib, uint8_t* out, int ob, int n, int c, int h,
                              int w, int k, int s, int relu_zp);
 
@@ -310,9 +311,7 @@ int i8ie_maxpool2d_u8_nhwc(i8ie_ctx* ctx, const uint8_t* in, int in_border, uint
   I8IE_REQUIRE(aligned16(in) && aligned16(out), "buffers must be 16-byte aligned");
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
   const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
-  if (out_border > 0)
-    I8IE_HIP_TRY(hipMemsetAsync(out, border_value, (size_t)n * (oh + 2 * out_border) * (ow + 2 * out_border) * c,
-                                ctx->stream));
+  I8IE_TRY(i8ie_launch_fill_border(ctx, out, n, c, oh, ow, out_border, border_value));
   return i8ie_launch_maxpool_nhwc(ctx, in, in_border, out, out_border, n, c, h, w, k, s, 0);
 }
 
@@ -471,7 +470,6 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
   const size_t in_bytes = (size_t)m * cg.c * cg.h * cg.w;
   const size_t out_bytes = (size_t)m * cg.kc * cg.oh * cg.ow;
-  const size_t out_phys = (size_t)m * cg.kc * (cg.oh + 2 * out_border) * (cg.ow + 2 * out_border);
   const int path = force_fallback(ctx) ? PATH_F : L->path;
 
   if (path == PATH_F) {
@@ -492,7 +490,7 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
                          col, ipc));
     if (relu) I8IE_TRY(i8ie_relu_u8(ctx, dst, dst, (int64_t)out_bytes, L->zp_out));
     if (o_bytes) {
-      if (out_border > 0) I8IE_HIP_TRY(hipMemsetAsync(out, L->zp_out, out_phys, ctx->stream));
+      I8IE_TRY(i8ie_launch_fill_border(ctx, out, m, cg.kc, cg.oh, cg.ow, out_border, L->zp_out));
       I8IE_TRY(i8ie_launch_nchw_to_nhwc(ctx, dst, out, m, cg.kc, cg.oh, cg.ow, out_border));
     }
     return I8IE_OK;
@@ -549,7 +547,7 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
       // weights-stationary small-C kernel (i8ie_first.hip) on the grouped image
       uint8_t* dst = o_bytes ? ws + t_bytes + r_bytes : out;
       const int ob = o_bytes ? 0 : out_border;
-      if (!o_bytes && out_border > 0) I8IE_HIP_TRY(hipMemsetAsync(out, L->zp_out, out_phys, ctx->stream));
+      if (!o_bytes) I8IE_TRY(i8ie_launch_fill_border(ctx, out, m, cg.kc, cg.oh, cg.ow, out_border, L->zp_out));
       I8ieFirstCall f{};
       f.x = nullptr; f.grouped = rep; f.scratch = nullptr;
       f.n = m; f.c = cg.c; f.h = cg.h; f.w = cg.w; f.q_scale = s_in; f.q_zp = zp_in;
@@ -568,7 +566,7 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
     c.out = o_bytes ? ws + t_bytes + r_bytes : out;
   }
   c.ob = o_bytes ? 0 : out_border;
-  if (!o_bytes && out_border > 0) I8IE_HIP_TRY(hipMemsetAsync(out, L->zp_out, out_phys, ctx->stream));
+  if (!o_bytes) I8IE_TRY(i8ie_launch_fill_border(ctx, out, m, cg.kc, cg.oh, cg.ow, out_border, L->zp_out));
   I8IE_TRY(i8ie_igemm_launch(ctx, c));
   if (o_bytes) I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, c.out, out, m, cg.kc, cg.oh, cg.ow, 0));
   return I8IE_OK;
@@ -600,9 +598,7 @@ int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, i
   I8IE_TRY(ensure_offsets(L, q_scale, q_zp));
   ConvGeom cg;
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
-  if (out_border > 0)
-    I8IE_HIP_TRY(hipMemsetAsync(out, L->zp_out,
-                                (size_t)m * cg.kc * (cg.oh + 2 * out_border) * (cg.ow + 2 * out_border), ctx->stream));
+  I8IE_TRY(i8ie_launch_fill_border(ctx, out, m, cg.kc, cg.oh, cg.ow, out_border, L->zp_out));
   I8IE_TRY(i8ie_ws_reserve(ctx, i8ie_first_scratch_bytes(m, cg.kh, L->kwg, cg.stride, cg.oh, cg.ow) + 256));
   I8ieFirstCall c{};
   c.x = in; c.grouped = nullptr; c.scratch = (uint8_t*)ctx->ws;

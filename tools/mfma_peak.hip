@@ -7,6 +7,9 @@
 //   mode 4: as 3, writes placed before each MFMA group
 //   mode 5: barrier only, no writes (what LDS-DMA staging could approach)
 //   mode 6: as 3 with fragment double-buffering (next k-step's reads issued before the MFMAs)
+//   mode 7: staging by LDS-DMA: 8 x global_load_lds_dwordx4 per thread per tile (L2-resident source),
+//           issued before the MFMAs, vmcnt(0) + barrier after them; no ds_write at all
+//   mode 8: as 7 with the DMA issue spread over the k-steps (2 per k-step)
 // build: hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,7 +18,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(int iters, int* out) {
+__global__ __launch_bounds__(256) void k(int iters, int* out, const unsigned char* gsrc) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 256 * 144];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   v16i acc[2][2];
@@ -31,7 +34,15 @@ __global__ __launch_bounds__(256) void k(int iters, int* out) {
   v4i st[8];
   for (int i = 0; i < 8; ++i) st[i] = v4i{tid + i, i, 3, 4};
   v4i a2[2], b2[2];
+  // DMA: lane's global source (1 KiB per wave-instruction, 16 B per lane), L2-resident 64 KiB window per block
+  const unsigned char* gp = gsrc + (size_t)(blockIdx.x & 255) * 65536 + tid * 16;
   for (int it = 0; it < iters; ++it) {
+    if (MODE == 7) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + ((it * 8 + i) & 15) * 4096),
+                                         (__attribute__((address_space(3))) void*)(smem + 256 * 144 + wave * 1024 + i * 4096), 16, 0, 0);
+    }
     if (MODE == 6) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const v4i*>(smem + ard[m]);
@@ -51,6 +62,12 @@ __global__ __launch_bounds__(256) void k(int iters, int* out) {
         for (int m = 0; m < 2; ++m) a2[m] = *reinterpret_cast<const v4i*>(smem + (ks + 1) * 32 + ard[m]);
 #pragma unroll
         for (int n = 0; n < 2; ++n) b2[n] = *reinterpret_cast<const v4i*>(smem + (ks + 1) * 32 + brd[n]);
+      }
+      if (MODE == 8) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + ((it * 8 + 2 * ks) & 15) * 4096),
+                                         (__attribute__((address_space(3))) void*)(smem + 256 * 144 + wave * 1024 + (2 * ks) * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + ((it * 8 + 2 * ks + 1) & 15) * 4096),
+                                         (__attribute__((address_space(3))) void*)(smem + 256 * 144 + wave * 1024 + (2 * ks + 1) * 4096), 16, 0, 0);
       }
       if (MODE == 4) {
         *reinterpret_cast<v4i*>(smem + 256 * 144 + wr + (2 * ks) * 32 * 144) = st[2 * ks] ^ (int)0x80808080;
@@ -84,15 +101,18 @@ __global__ __launch_bounds__(256) void k(int iters, int* out) {
 template <int MODE>
 void run(const char* name, int blocks_per_cu) {
   int* out;
+  unsigned char* gsrc;
   const int blocks = 256 * blocks_per_cu, iters = 2000;
   hipMalloc(&out, blocks * 256 * 4);
+  hipMalloc(&gsrc, 256 * 65536 + 65536);
+  hipMemset(gsrc, 1, 256 * 65536 + 65536);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  k<MODE><<<blocks, 256>>>(200, out);
+  k<MODE><<<blocks, 256>>>(200, out, gsrc);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k<MODE><<<blocks, 256>>>(iters, out);
+  k<MODE><<<blocks, 256>>>(iters, out, gsrc);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -100,6 +120,7 @@ void run(const char* name, int blocks_per_cu) {
   const double ops = (double)blocks * 4 * iters * 16 * 65536.0;
   printf("%-28s blocks/CU %d: %.3f ms  %.0f TOPS\n", name, blocks_per_cu, ms, ops / (ms * 1e-3) / 1e12);
   hipFree(out);
+  hipFree(gsrc);
 }
 
 int main() {
@@ -111,6 +132,8 @@ int main() {
     run<4>("writes spread before mfma", b);
     run<5>("reads + barrier, no writes", b);
     run<6>("spread writes + frag dbuf", b);
+    run<7>("LDS-DMA staging, up front", b);
+    run<8>("LDS-DMA staging, spread", b);
   }
   return 0;
 }
