@@ -179,9 +179,17 @@ def main():
     dom = max(mfma, key=lambda k: mfma[k]["ms"])
     d = mfma[dom]
     achieved = d["ops"] / (d["ms"] * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    try:  # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE), collected offline
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if tj.get("kernel") == dom and n_total == 1000 and world == 1:
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = {
         "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": INT8_DENSE_PEAK_TOPS,
-        "unit": "TFLOP/s", "frac": round(achieved / INT8_DENSE_PEAK_TOPS, 4), "traffic": None,
+        "unit": "TFLOP/s", "frac": round(achieved / INT8_DENSE_PEAK_TOPS, 4), "traffic": traffic,
+        "traffic_source": traffic_src,
         "ops_per_launch": d["ops"] / d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
         "launches_per_step": d["launches"] / args.steps,
     }
