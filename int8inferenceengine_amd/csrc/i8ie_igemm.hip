@@ -102,6 +102,10 @@ struct IgemmArgs {
   uint8_t* out;  // [M][N], or bordered NHWC when ob > 0
   int ob, OHp, OWp;
   int32_t* acc;  // [M][N]
+  // split-K (Linear with few output tiles): blockIdx.y = K slice; slices write INT32 partial slabs
+  // [slice][M][N] to `partial` and skip the epilogue; splitk_reduce_kernel finishes
+  int ksplit, tiles_per_slice;
+  int32_t* partial;
 };
 
 // VAR (tuning variants, identical results): 0 = two LDS stages, loads one K tile ahead;
@@ -145,7 +149,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int gcol = nb + (r & 3) + 8 * (r >> 2);
-      const int init = gcol < p.N ? p.ocp[gcol] : 0;  // (unconditional loads here make hipcc double the AGPRs)
+      // (unconditional loads here make hipcc double the AGPRs); K slices > 0 of a split-K launch start at 0
+      const int init = (gcol < p.N && blockIdx.y == 0) ? p.ocp[gcol] : 0;
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) acc[mi][ni][r] = init;
     }
@@ -189,13 +194,14 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
 
   v4i ra[A_PER], rb[B_PER];
   v4i ra2[VAR == 1 ? A_PER : 1], rb2[VAR == 1 ? B_PER : 1];  // second register set (VAR 1)
+  int kbase_l = 0;  // set below once the K slice of this block is known
   auto load_into = [&](int k0, v4i* da, v4i* db) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i)
       da[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsA, a_off[i] + koff, 0, 0));
 #pragma unroll
     for (int i = 0; i < B_PER; ++i)
-      db[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], k0, 0));
+      db[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], k0 + kbase_l, 0));
     koff += BK2;
     if (AMODE == 1) {
       f += 8;
@@ -260,7 +266,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
-  const int nk = p.Kpad / BK2;
+  int nk = p.Kpad / BK2;
+  int kbase = 0;  // first K byte of this block's slice
+  if (AMODE == 0 && p.ksplit > 1) {
+    const int t0 = blockIdx.y * p.tiles_per_slice;
+    const int t1 = t0 + p.tiles_per_slice < nk ? t0 + p.tiles_per_slice : nk;
+    kbase = t0 * BK2;
+    nk = t1 - t0;  // >= 1 by construction
+    koff += kbase;
+    kbase_l = kbase;
+  }
   if constexpr (VAR == 3) {  // one stage: compute | barrier | refill | barrier
     load_tile(0);
     store_tile(S0{});
@@ -305,6 +320,22 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
       if (kt + 2 < nk) store_tile(S0{});
       __syncthreads();
     }
+  }
+
+  if (AMODE == 0 && p.ksplit > 1) {  // split-K: raw INT32 partial sums, finished by splitk_reduce_kernel
+    int32_t* slab = p.partial + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int grow = m0 + (wm * TM + mi) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gcol = n0 + (wn * TN + ni) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (grow < p.M && gcol < p.N) slab[(size_t)grow * p.N + gcol] = acc[mi][ni][r];
+        }
+      }
+    return;
   }
 
   // ---- epilogue: (bias) -> requant -> (relu) -> LDS tile [BM][BN] -> 16-B row stores ----
@@ -538,6 +569,35 @@ __global__ __launch_bounds__(64) void finish_offsets_kernel(const int32_t* __res
   if (biasf != nullptr) biasf[j] = (float)qb[j] / s_in;
 }
 
+// split-K finish: C = sum of the slices' partials (slice 0 carries ocp), then the Linear epilogue of
+// src/fully_connected.cc:42-48 on 4 consecutive features per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const int32_t* __restrict__ partial, int ksplit, int M,
+                                                            int N, const float* __restrict__ biasf, Requant rq,
+                                                            int relu_lo, uint8_t* __restrict__ out,
+                                                            int32_t* __restrict__ acc) {
+  const int64_t total = (int64_t)M * N;
+  const int64_t gstride = (int64_t)gridDim.x * 256;
+  const float lof = (float)relu_lo;
+  for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < total; e += gstride * 4) {
+    int cv[4];
+    const int nvalid = total - e < 4 ? (int)(total - e) : 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int c = 0;
+      if (r < nvalid) {
+        for (int s = 0; s < ksplit; ++s) c += partial[(size_t)s * total + e + r];
+        if (acc != nullptr) acc[e + r] = c;
+        if (biasf != nullptr) c = (int)((float)c + biasf[(e + r) % N]);
+      }
+      cv[r] = c;
+    }
+    const uint32_t packed = requant_pack4(cv, rq, relu_lo, lof);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < nvalid) out[e + r] = (uint8_t)(packed >> (8 * r));
+  }
+}
+
 inline int cap_grid(int64_t items, int threads, int max_blocks = 256 * 16) {
   int64_t b = (items + threads - 1) / threads;
   if (b < 1) b = 1;
@@ -553,20 +613,29 @@ int launch_cfg(i8ie_ctx* ctx, const IgemmArgs& a, const char* name, int kbytes, 
   snprintf(tag, sizeof(tag), "%s|M%d,N%d,K%d", name, a.M, a.N, kbytes);
   I8ieProfScope prof(ctx, ctx->prof ? tag : name, ops, bytes);
   igemm_u8s8_kernel<AMODE, WM, WN, TM, TN, BIAS, ACC, VAR>
-      <<<tiles_m * tiles_n, WM * WN * 64, 0, ctx->stream>>>(a, tiles_m, tiles_n, m_fastest);
+      <<<dim3(tiles_m * tiles_n, a.ksplit > 1 ? a.ksplit : 1), WM * WN * 64, 0, ctx->stream>>>(a, tiles_m, tiles_n,
+                                                                                             m_fastest);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }
 
 template <int AMODE, bool BIAS, bool ACC, int VAR>
 int launch_tile_var(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, double bytes) {
-  if (a.N <= 32)
+  // widest N tile that still gives the chip enough blocks: small-M Linear layers (one or a few M tiles)
+  // otherwise run on N/128 blocks only (M = 125, N = 4096: 32 blocks on 256 CUs)
+  const long tiles_m = (a.M + 127) / 128;
+  int bn = a.N <= 32 ? 32 : a.N <= 64 ? 64 : a.N <= 96 ? 96 : 128;
+  if (AMODE == 0 && bn == 128) {
+    if (tiles_m * ((a.N + 127) / 128) < 512) bn = 64;
+    if (tiles_m * ((a.N + 63) / 64) < 256) bn = 32;
+  }
+  if (bn == 32)
     return launch_cfg<AMODE, 4, 1, 1, 1, BIAS, ACC, VAR>(ctx, a, AMODE ? "igemm_conv_128x32" : "igemm_lin_128x32", kbytes,
                                                          ops, bytes);
-  if (a.N <= 64)
+  if (bn == 64)
     return launch_cfg<AMODE, 2, 2, 2, 1, BIAS, ACC, VAR>(ctx, a, AMODE ? "igemm_conv_128x64" : "igemm_lin_128x64", kbytes,
                                                          ops, bytes);
-  if (a.N <= 96)
+  if (bn == 96)
     return launch_cfg<AMODE, 4, 1, 1, 3, BIAS, ACC, VAR>(ctx, a, AMODE ? "igemm_conv_128x96" : "igemm_lin_128x96", kbytes,
                                                          ops, bytes);
   return launch_cfg<AMODE, 2, 2, 2, 2, BIAS, ACC, VAR>(ctx, a, AMODE ? "igemm_conv_128x128" : "igemm_lin_128x128", kbytes,
@@ -608,6 +677,8 @@ struct I8ieIgemmCall {
   int ob;  // physical border of the NHWC output (AMODE 1 only)
   int32_t* acc;
   double Ktrue;
+  int ksplit;        // AMODE 0 only: > 1 = split K over that many slices (partial must hold ksplit*M*N int32)
+  int32_t* partial;
 };
 
 int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
@@ -653,6 +724,22 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   const double bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
   const int kb = c.Kchunks * 16;
   const bool bias = c.biasf != nullptr, accd = c.acc != nullptr;
+  if (c.amode == 0 && c.ksplit > 1 && c.partial != nullptr) {
+    const int nk = c.Kpad / BK2;
+    a.tiles_per_slice = (nk + c.ksplit - 1) / c.ksplit;
+    a.ksplit = (nk + a.tiles_per_slice - 1) / a.tiles_per_slice;
+    a.partial = c.partial;
+    if (a.ksplit > 1) {
+      I8IE_TRY((launch_tile<0, false, false>(ctx, a, kb, ops, bytes)));
+      I8ieProfScope prof(ctx, "splitk_reduce", 0.0, 4.0 * a.ksplit * c.M * c.N + (double)c.M * c.N);
+      const int64_t quads = ((int64_t)c.M * c.N + 3) / 4;
+      splitk_reduce_kernel<<<cap_grid(quads, 256), 256, 0, ctx->stream>>>(c.partial, a.ksplit, c.M, c.N, c.biasf, a.rq,
+                                                                          a.relu_lo, c.out, c.acc);
+      I8IE_LAUNCH_CHECK();
+      return I8IE_OK;
+    }
+    a.ksplit = 0;
+  }
   if (c.amode == 0) {
     if (bias)
       return accd ? launch_tile<0, true, true>(ctx, a, kb, ops, bytes) : launch_tile<0, true, false>(ctx, a, kb, ops, bytes);

@@ -53,6 +53,8 @@ struct I8ieIgemmCall {
   int ob;
   int32_t* acc;
   double Ktrue;
+  int ksplit;
+  int32_t* partial;
 };
 int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 
@@ -446,8 +448,21 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
       return I8IE_OK;
     }
     I8ieIgemmCall c{};
+    // split K when the output has too few tiles to fill the chip (small batch, or few features)
+    const long tiles_m = (m + 127) / 128, blocks_est = tiles_m * ((L->n + 63) / 64);
+    const int nk = L->Kpad / 128;
+    int ksplit = 1;
+    if (blocks_est < 256 && nk >= 4) {
+      ksplit = (int)((512 + blocks_est - 1) / blocks_est);
+      if (ksplit > 8) ksplit = 8;
+      if (ksplit > nk / 2) ksplit = nk / 2;
+    }
+    const size_t pad_bytes = need_pad ? i8ie_align_up((size_t)m * L->Kpad, 256) : 0;
+    const size_t part_bytes = ksplit > 1 ? (size_t)ksplit * m * L->n * 4 : 0;
+    if (pad_bytes + part_bytes) I8IE_TRY(i8ie_ws_reserve(ctx, pad_bytes + part_bytes));
+    c.ksplit = ksplit;
+    c.partial = ksplit > 1 ? (int32_t*)((uint8_t*)ctx->ws + pad_bytes) : nullptr;
     if (need_pad) {
-      I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->Kpad));
       I8IE_TRY(i8ie_launch_pad_rows(ctx, in, m, L->K, ctx->ws, m, L->Kpad, 0));
       c.A = (const uint8_t*)ctx->ws;
       c.lda = L->Kpad;
