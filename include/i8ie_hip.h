@@ -186,9 +186,10 @@ int i8ie_layer_forward(i8ie_layer* layer, const uint8_t* in_dev, int m, int h, i
  * NHWC; an NHWC tensor may carry a physical border of `border` pixels on each side of H and W
  * ([n][h+2b][w+2b][c]) whose bytes hold the tensor's zero point: a conv whose input border
  * covers its padding gathers with no bounds checks (the pad-with-zero-point rule of
- * src/conv2d.cc:24-28 is materialised by the producer).  When out_border > 0 this call fills
- * the border of `out` with zp_out.  i8ie_layer_preferred_layout tells which output layout
- * avoids a conversion. */
+ * src/conv2d.cc:24-28 is materialised by the producer).  When out_border > 0 the call writes
+ * only the interior of `out`: the border bytes are the caller's (i8ie_fill_border_u8 with
+ * zp_out, once per buffer: they stay valid while the buffer is reused for the same tensor).
+ * i8ie_layer_preferred_layout tells which output layout avoids a conversion. */
 int i8ie_layer_forward_fused(i8ie_layer* layer, const uint8_t* in_dev, int in_layout, int in_border, int m,
                              int h, int w, float s_in, uint8_t zp_in, int relu, uint8_t* out_dev,
                              int out_layout, int out_border, int32_t* acc_dbg_dev);
@@ -196,7 +197,7 @@ int i8ie_layer_preferred_layout(const i8ie_layer* layer, int* layout);
 /* First layer fused with the input quantisation (Module.__call__ quantises the FP32 input with
  * 0.025 / 127, i8ie/module.py:20, and hands it straight to the first Conv2d): reads FP32 NCHW,
  * computes q = (u8)(x / q_scale + q_zp) exactly as src/quantize_utils.cc:44-52 and the conv of
- * src/conv2d.cc:100-142 on it, writes NHWC u8 (+ optional border / relu).  Only for layers and
+ * src/conv2d.cc:100-142 on it, writes the interior of an NHWC u8 tensor (+ optional relu).  Only for layers and
  * geometries where i8ie_layer_accepts_f32_input says yes (<= 3 channels, stride % 4 == 0,
  * out features % 32 == 0): AlexNet's 11x11 stride-4 conv1.  Identical bytes to
  * i8ie_quantize_f32_u8 followed by i8ie_layer_forward_fused. */
@@ -212,11 +213,13 @@ int i8ie_layer_destroy(i8ie_layer* layer);
  * of the destination is filled with border_value) */
 int i8ie_layout_convert_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int n, int c, int h,
                            int w, int to_nhwc, int border, uint8_t border_value);
+/* border bytes of a bordered NHWC u8 tensor [n,h+2b,w+2b,c] := value (interior untouched) */
+int i8ie_fill_border_u8(i8ie_ctx* ctx, uint8_t* buf_dev, int n, int c, int h, int w, int border,
+                        uint8_t value);
 /* max_pool2d<u8_t> (src/functional.cc:36-64) on NHWC data, channels % 16 == 0; h, w are the
- * logical input dims; the output border (if any) is filled with border_value */
+ * logical input dims; only the interior of a bordered output is written */
 int i8ie_maxpool2d_u8_nhwc(i8ie_ctx* ctx, const uint8_t* in_dev, int in_border, uint8_t* out_dev,
-                           int out_border, int n, int c, int h, int w, int kernel_size, int stride,
-                           uint8_t border_value);
+                           int out_border, int n, int c, int h, int w, int kernel_size, int stride);
 
 #ifdef __cplusplus
 }

@@ -303,8 +303,15 @@ int i8ie_layout_convert_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n
   return i8ie_launch_nhwc_to_nchw(ctx, in, out, n, c, h, w, border);
 }
 
+int i8ie_fill_border_u8(i8ie_ctx* ctx, uint8_t* buf, int n, int c, int h, int w, int border, uint8_t value) {
+  I8IE_REQUIRE(ctx && buf, "null argument");
+  I8IE_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && border >= 0, "bad dimension");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  return i8ie_launch_fill_border(ctx, buf, n, c, h, w, border, value);
+}
+
 int i8ie_maxpool2d_u8_nhwc(i8ie_ctx* ctx, const uint8_t* in, int in_border, uint8_t* out, int out_border, int n,
-                           int c, int h, int w, int k, int s, uint8_t border_value) {
+                           int c, int h, int w, int k, int s) {
   I8IE_REQUIRE(ctx && in && out, "null argument");
   I8IE_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0 && in_border >= 0 && out_border >= 0, "bad dimension");
   I8IE_REQUIRE(c % 16 == 0, "NHWC max-pool needs channels % 16 == 0");
@@ -312,8 +319,6 @@ int i8ie_maxpool2d_u8_nhwc(i8ie_ctx* ctx, const uint8_t* in, int in_border, uint
   I8IE_REQUIRE(k <= h && k <= w, "window larger than the input");
   I8IE_REQUIRE(aligned16(in) && aligned16(out), "buffers must be 16-byte aligned");
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
-  const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
-  I8IE_TRY(i8ie_launch_fill_border(ctx, out, n, c, oh, ow, out_border, border_value));
   return i8ie_launch_maxpool_nhwc(ctx, in, in_border, out, out_border, n, c, h, w, k, s, 0);
 }
 
@@ -505,7 +510,6 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
                          col, ipc));
     if (relu) I8IE_TRY(i8ie_relu_u8(ctx, dst, dst, (int64_t)out_bytes, L->zp_out));
     if (o_bytes) {
-      I8IE_TRY(i8ie_launch_fill_border(ctx, out, m, cg.kc, cg.oh, cg.ow, out_border, L->zp_out));
       I8IE_TRY(i8ie_launch_nchw_to_nhwc(ctx, dst, out, m, cg.kc, cg.oh, cg.ow, out_border));
     }
     return I8IE_OK;
@@ -562,7 +566,6 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
       // weights-stationary small-C kernel (i8ie_first.hip) on the grouped image
       uint8_t* dst = o_bytes ? ws + t_bytes + r_bytes : out;
       const int ob = o_bytes ? 0 : out_border;
-      if (!o_bytes) I8IE_TRY(i8ie_launch_fill_border(ctx, out, m, cg.kc, cg.oh, cg.ow, out_border, L->zp_out));
       I8ieFirstCall f{};
       f.x = nullptr; f.grouped = rep; f.scratch = nullptr;
       f.n = m; f.c = cg.c; f.h = cg.h; f.w = cg.w; f.q_scale = s_in; f.q_zp = zp_in;
@@ -581,7 +584,6 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
     c.out = o_bytes ? ws + t_bytes + r_bytes : out;
   }
   c.ob = o_bytes ? 0 : out_border;
-  if (!o_bytes) I8IE_TRY(i8ie_launch_fill_border(ctx, out, m, cg.kc, cg.oh, cg.ow, out_border, L->zp_out));
   I8IE_TRY(i8ie_igemm_launch(ctx, c));
   if (o_bytes) I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, c.out, out, m, cg.kc, cg.oh, cg.ow, 0));
   return I8IE_OK;
@@ -613,7 +615,6 @@ int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, i
   I8IE_TRY(ensure_offsets(L, q_scale, q_zp));
   ConvGeom cg;
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
-  I8IE_TRY(i8ie_launch_fill_border(ctx, out, m, cg.kc, cg.oh, cg.ow, out_border, L->zp_out));
   I8IE_TRY(i8ie_ws_reserve(ctx, i8ie_first_scratch_bytes(m, cg.kh, L->kwg, cg.stride, cg.oh, cg.ow) + 256));
   I8ieFirstCall c{};
   c.x = in; c.grouped = nullptr; c.scratch = (uint8_t*)ctx->ws;

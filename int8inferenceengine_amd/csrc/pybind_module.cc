@@ -23,6 +23,7 @@
 #include <cstring>
 #include <functional>
 #include <iostream>
+#include <map>
 #include <memory>
 #include <random>
 #include <stdexcept>
@@ -73,9 +74,25 @@ i8ie_ctx* ctx() {
 // py::capsule in include/tensor.h:28,94-104).  A host mirror is kept for
 // tensors that came from numpy so that small host-side round trips
 // (argmax / == / sum in i8ie/__init__.py) do not touch the device.
+struct Storage;
+// Bordered NHWC buffers whose border bytes already hold the zero point, keyed by geometry: a network that
+// runs the same shapes again gets them back and skips the border fill (kernels only write interiors).
+struct BorderKey {
+  size_t bytes;
+  int n, c, h, w, b, zp;
+  bool operator<(const BorderKey& o) const {
+    return std::tie(bytes, n, c, h, w, b, zp) < std::tie(o.bytes, o.n, o.c, o.h, o.w, o.b, o.zp);
+  }
+};
+std::map<BorderKey, std::vector<void*>>& border_cache() {
+  static auto* m = new std::map<BorderKey, std::vector<void*>>();
+  return *m;
+}
+
 struct Storage {
   size_t bytes = 0;
   void* dev = nullptr;
+  int bzp = -1;  // >= 0: bordered NHWC buffer with border bytes == bzp (returns to border_cache)
   std::vector<unsigned char> host;
   bool host_valid = false;
   // physical layout of a 4-D u8 activation: the engine keeps NHWC between layers and
@@ -99,9 +116,18 @@ struct Storage {
     bytes = logical;
     layout = I8IE_LAYOUT_NCHW;
     border = 0;
+    bzp = -1;
   }
   ~Storage() {
-    if (dev && rt().ctx) i8ie_free(rt().ctx, dev);
+    if (!dev || !rt().ctx) return;
+    if (bzp >= 0 && layout == I8IE_LAYOUT_NHWC && border > 0) {
+      auto& slot = border_cache()[BorderKey{bytes, dn, dc, dh, dw, border, bzp}];
+      if (slot.size() < 4) {
+        slot.push_back(dev);
+        return;
+      }
+    }
+    i8ie_free(rt().ctx, dev);
   }
   void* device_ptr() {
     if (!dev) {
@@ -131,6 +157,29 @@ std::shared_ptr<Storage> device_storage(size_t bytes) {
   auto s = std::make_shared<Storage>();
   s->bytes = bytes;
   check(i8ie_malloc(ctx(), bytes, &s->dev));
+  return s;
+}
+
+// NHWC u8 storage for logical shape `shp` (NCHW order) with a border of b pixels holding zp
+std::shared_ptr<Storage> nhwc_storage(const std::vector<ssize_t>& shp, int b, int zp) {
+  const size_t bytes = (size_t)shp[0] * shp[1] * (shp[2] + 2 * b) * (shp[3] + 2 * b);
+  if (b <= 0) {
+    auto s = device_storage(bytes);
+    s->set_nhwc(shp, 0);
+    return s;
+  }
+  auto s = std::make_shared<Storage>();
+  s->bytes = bytes;
+  s->set_nhwc(shp, b);
+  s->bzp = zp;
+  auto it = border_cache().find(BorderKey{bytes, s->dn, s->dc, s->dh, s->dw, b, zp});
+  if (it != border_cache().end() && !it->second.empty()) {
+    s->dev = it->second.back();  // border still valid from its previous life
+    it->second.pop_back();
+    return s;
+  }
+  check(i8ie_malloc(ctx(), bytes, &s->dev));
+  check(i8ie_fill_border_u8(ctx(), (uint8_t*)s->dev, s->dn, s->dc, s->dh, s->dw, b, (uint8_t)zp));
   return s;
 }
 
@@ -336,10 +385,9 @@ Tensor<u8_t> max_pool2d_u8(Tensor<u8_t>& in, ssize_t k, ssize_t s) {  // src/fun
         std::shared_ptr<Storage> st;
         const size_t logical = (size_t)oshp[0] * oshp[1] * oshp[2] * oshp[3];
         if (src.st->layout == I8IE_LAYOUT_NHWC && ishp[1] % 16 == 0) {
-          st = device_storage((size_t)oshp[0] * oshp[1] * (oshp[2] + 2 * border) * (oshp[3] + 2 * border));
+          st = nhwc_storage(oshp, border, zp);
           check(i8ie_maxpool2d_u8_nhwc(ctx(), ip, src.st->border, (uint8_t*)st->dev, border, (int)ishp[0], (int)ishp[1],
-                                       (int)ishp[2], (int)ishp[3], kk, ss, zp));
-          st->set_nhwc(oshp, border);
+                                       (int)ishp[2], (int)ishp[3], kk, ss));
         } else {
           st = device_storage(logical);
           check(i8ie_maxpool2d_u8(ctx(), src.dptr(), (uint8_t*)st->dev, (int)ishp[0], (int)ishp[1], (int)ishp[2],
@@ -509,10 +557,11 @@ class BaseLayer {
     Tensor<u8_t> src = in;  // shares the input's storage / pending launch
     const float s_in = in.scale;
     const u8_t zp_in = in.zero_point;
+    const int zp_out = zero_point_;
     const std::vector<ssize_t> oshp = out.shape;
     const size_t obytes = (size_t)out.size;
     out.pend = std::make_shared<std::function<std::shared_ptr<Storage>(bool, int)>>(
-        [handle, src, s_in, zp_in, m, h, w, spatial, oshp, obytes](bool relu, int border) mutable {
+        [handle, src, s_in, zp_in, zp_out, m, h, w, spatial, oshp, obytes](bool relu, int border) mutable {
           int out_layout = I8IE_LAYOUT_NCHW, pad = 0;
           if (spatial) {
             check(i8ie_layer_preferred_layout(handle.get(), &out_layout));
@@ -522,11 +571,9 @@ class BaseLayer {
             int yes = 0;
             check(i8ie_layer_accepts_f32_input(handle.get(), h, w, &yes));
             if (yes) {  // quantize + conv (+ relu) in one kernel, reading the FP32 input
-              const size_t phys = (size_t)oshp[0] * oshp[1] * (oshp[2] + 2 * border) * (oshp[3] + 2 * border);
-              auto st = device_storage(phys);
+              auto st = nhwc_storage(oshp, border, zp_out);
               check(i8ie_layer_forward_f32_input(handle.get(), (const float*)src.qsrc->device_ptr(), m, h, w,
                                                  src.qscale, src.qzp, relu ? 1 : 0, (uint8_t*)st->dev, border));
-              st->set_nhwc(oshp, border);
               src = Tensor<u8_t>();
               return st;
             }
@@ -541,12 +588,9 @@ class BaseLayer {
           }
           const int in_layout = src.st->layout, in_border = src.st->border;
           const int ob = out_layout == I8IE_LAYOUT_NHWC ? border : 0;
-          const size_t phys = out_layout == I8IE_LAYOUT_NHWC
-                                  ? (size_t)oshp[0] * oshp[1] * (oshp[2] + 2 * ob) * (oshp[3] + 2 * ob) : obytes;
-          auto st = device_storage(phys);
+          auto st = out_layout == I8IE_LAYOUT_NHWC ? nhwc_storage(oshp, ob, zp_out) : device_storage(obytes);
           check(i8ie_layer_forward_fused(handle.get(), ip, in_layout, in_border, m, h, w, s_in, zp_in, relu ? 1 : 0,
                                          (uint8_t*)st->dev, out_layout, ob, nullptr));
-          if (out_layout == I8IE_LAYOUT_NHWC) st->set_nhwc(oshp, ob);
           src = Tensor<u8_t>();  // release the input as soon as the launch is queued
           return st;
         });
@@ -786,7 +830,12 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
     check(i8ie_memory_stats(ctx(), &live, &cached, &allocs));
     return py::make_tuple(live, cached, allocs);
   });
-  m.def("trim", []() { check(i8ie_trim(ctx())); });
+  m.def("trim", []() {
+    for (auto& kv : border_cache())
+      for (void* p : kv.second) i8ie_free(ctx(), p);
+    border_cache().clear();
+    check(i8ie_trim(ctx()));
+  });
   m.def("force_fallback", [](bool on) { check(i8ie_ctx_set_option(ctx(), I8IE_OPT_FORCE_FALLBACK, on ? 1 : 0)); });
   m.def("profile_start", [](bool mfma_only) { check(i8ie_profile_start(ctx(), mfma_only ? 1 : 0)); },
         py::arg("mfma_only") = false);

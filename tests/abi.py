@@ -248,7 +248,8 @@ class Ctx:
         h, w = hp - 2 * in_border, wp - 2 * in_border
         oh, ow = (h - k) // s + 1, (w - k) // s + 1
         d, o = self.put(q), self.empty((n, oh + 2 * out_border, ow + 2 * out_border, c), np.uint8)
-        ck(lib().i8ie_maxpool2d_u8_nhwc(self.h, d.ptr, in_border, o.ptr, out_border, n, c, h, w, k, s, C.c_uint8(fill)))
+        ck(lib().i8ie_fill_border_u8(self.h, o.ptr, n, c, oh, ow, out_border, C.c_uint8(fill)))
+        ck(lib().i8ie_maxpool2d_u8_nhwc(self.h, d.ptr, in_border, o.ptr, out_border, n, c, h, w, k, s))
         r = o.get()
         d.free(); o.free()
         return r
@@ -291,6 +292,9 @@ class Ctx:
         di = self.put(phys_in)
         out = self.empty(oshape, np.uint8)
         acc = self.empty(ashape, np.int32) if want_acc else None
+        if kind != "linear" and out_nhwc and out_border:
+            ck(lib().i8ie_fill_border_u8(self.h, out.ptr, m, oshape[3], oshape[1] - 2 * out_border,
+                                         oshape[2] - 2 * out_border, out_border, C.c_uint8(zp_out)))
         ck(lib().i8ie_layer_forward_fused(L, di.ptr, 1 if in_nhwc else 0, in_border, m, h, w, C.c_float(s_in),
                                           C.c_uint8(zp_in), 1 if relu else 0, out.ptr, 1 if out_nhwc else 0,
                                           out_border, acc.ptr if acc else None))

@@ -34,6 +34,7 @@ def run_first(gpu, x, qw, qb, stride, pad, q_scale, q_zp, s_w, s_out, zp_out, re
         return None
     dx = gpu.put(np.ascontiguousarray(x, np.float32))
     out = gpu.empty((n, oh + 2 * ob, ow + 2 * ob, kc), np.uint8)
+    abi.ck(lib.i8ie_fill_border_u8(gpu.h, out.ptr, n, kc, oh, ow, ob, C.c_uint8(zp_out)))
     abi.ck(lib.i8ie_layer_forward_f32_input(L, dx.ptr, n, h, w, C.c_float(q_scale), C.c_uint8(q_zp), 1 if relu else 0,
                                             out.ptr, ob))
     phys = out.get()
