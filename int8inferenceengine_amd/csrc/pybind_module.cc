@@ -524,6 +524,32 @@ class BaseLayer {
     if (q_) check(i8ie_layer_set_output_qparams(q_.get(), scale_, zero_point_));
   }
   std::tuple<float, int> output_qparams() const { return std::make_tuple(scale_, (int)zero_point_); }
+  // additive: restore a converted layer from saved INT8 weights (what convert() would have produced)
+  void load_quantized(py::array_t<s8_t, py::array::c_style | py::array::forcecast> qw,
+                      py::array_t<s8_t, py::array::c_style | py::array::forcecast> qb, float w_scale, float s_out,
+                      int zp_out) {
+    if (zp_out < 0 || zp_out > 255) throw std::runtime_error("i8ie: zero point must be in [0, 255]");
+    std::vector<ssize_t> shp(qw.shape(), qw.shape() + qw.ndim());
+    if (shp.size() != wshape_.size()) throw std::runtime_error("i8ie: load_quantized: weight rank mismatch");
+    wshape_ = shp;
+    if (qb.size() != wshape_[0]) throw std::runtime_error("i8ie: load_quantized: bias size mismatch");
+    qw_.assign(qw.data(), qw.data() + qw.size());
+    qb_.assign(qb.data(), qb.data() + qb.size());
+    w_scale_ = w_scale;
+    scale_ = s_out;
+    zero_point_ = (u8_t)zp_out;
+    qparams_overridden_ = true;
+    i8ie_layer* raw = make_handle((ssize_t)qb_.size());
+    q_ = std::shared_ptr<i8ie_layer>(raw, [](i8ie_layer* l) { i8ie_layer_destroy(l); });
+    check(i8ie_layer_set_output_qparams(q_.get(), scale_, zero_point_));
+    cal_.reset();
+    is_preparing_ = false;
+    is_quantized_ = true;
+    std::vector<float>().swap(w_);
+    std::vector<float>().swap(b_);
+    has_fp32_ = false;
+    release_fp32_dev();
+  }
   py::array_t<s8_t> q_weight() const {
     need_quantized();
     py::array_t<s8_t> a(wshape_);
@@ -762,6 +788,8 @@ void bind_layer_common(py::class_<L>& c) {
       .def("forward_debug", [](L& l, Tensor<u8_t>& x) { return l.forward_u8(x, true); })
       .def("set_output_qparams", &L::set_output_qparams, py::arg("scale"), py::arg("zero_point"))
       .def("output_qparams", &L::output_qparams)
+      .def("load_quantized", &L::load_quantized, py::arg("q_weight"), py::arg("q_bias"), py::arg("weight_scale"),
+           py::arg("out_scale"), py::arg("out_zero_point"))
       .def("q_weight", &L::q_weight)
       .def("q_bias", &L::q_bias)
       .def("weight_scale", &L::weight_scale)
