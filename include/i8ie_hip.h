@@ -58,6 +58,10 @@ int i8ie_sync(i8ie_ctx* ctx);
 /* I8IE_OPT_KERNEL_VARIANT = 2 selects among compiled variants of the contraction kernel (all
  * produce identical bytes; a tuning / A-B timing aid, 0 = default). */
 #define I8IE_OPT_KERNEL_VARIANT 2
+/* I8IE_OPT_PROFILE_STRIDE = 3: while profiling, bracket only every value-th eligible launch
+ * (default 1 = all).  Event packets cost a few microseconds each on the stream; a stride that is
+ * coprime with the launches per batch samples every kernel over a few batches. */
+#define I8IE_OPT_PROFILE_STRIDE 3
 int i8ie_ctx_set_option(i8ie_ctx* ctx, int option, int value);
 
 /* Activation layouts accepted by the *_fused / *_nhwc entry points.  NCHW is the
@@ -96,6 +100,28 @@ int i8ie_memcpy_h2d(i8ie_ctx* ctx, void* dst_dev, const void* src_host, size_t b
 int i8ie_memcpy_d2h(i8ie_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* waits */
 int i8ie_memcpy_d2d(i8ie_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 int i8ie_memset(i8ie_ctx* ctx, void* dst_dev, int byte, size_t bytes);
+
+/* ---- asynchronous host<->device transfers -------
+ * Nothing like it in the reference (its tensors are host arrays, include/tensor.h:26-61); this is
+ * what lets a caller overlap the logits read-back and the next batch's upload with the kernels.
+ * Host buffers given to the *_async copies must come from i8ie_host_malloc (pinned); a pageable
+ * pointer is refused with I8IE_ERR_ARG.  `on_copy_stream` != 0 issues the copy on the ctx's second
+ * (transfer) stream so that it runs beside the kernels; order it against the compute stream with
+ * events: record on one stream, i8ie_stream_wait_event on the other (device-side wait, the host
+ * does not block), or i8ie_event_synchronize to block the host until the recorded point. */
+typedef struct i8ie_event i8ie_event;
+int i8ie_host_malloc(i8ie_ctx* ctx, size_t bytes, void** host);
+int i8ie_host_free(i8ie_ctx* ctx, void* host);
+/* *yes = 1 when [p, p+bytes) lies inside one live i8ie_host_malloc block of this ctx */
+int i8ie_host_is_pinned(i8ie_ctx* ctx, const void* p, size_t bytes, int* yes);
+int i8ie_memcpy_h2d_async(i8ie_ctx* ctx, void* dst_dev, const void* src_pinned, size_t bytes, int on_copy_stream);
+int i8ie_memcpy_d2h_async(i8ie_ctx* ctx, void* dst_pinned, const void* src_dev, size_t bytes, int on_copy_stream);
+int i8ie_event_create(i8ie_ctx* ctx, i8ie_event** out);
+int i8ie_event_record(i8ie_ctx* ctx, i8ie_event* ev, int on_copy_stream);
+int i8ie_stream_wait_event(i8ie_ctx* ctx, i8ie_event* ev, int copy_stream_waits);
+int i8ie_event_synchronize(i8ie_event* ev);
+int i8ie_event_query(i8ie_event* ev, int* done);
+int i8ie_event_destroy(i8ie_event* ev);
 
 /* ---- elementwise ops ---------------------------------------------------- */
 /* quantize(Tensor<float>&, scale, zp)  src/quantize_utils.cc:44-52, src/pybind11.cc:41-45

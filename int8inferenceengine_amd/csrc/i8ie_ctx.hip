@@ -137,6 +137,15 @@ int i8ie_ctx_destroy(i8ie_ctx* ctx) {
   for (auto& kv : pool_of(ctx)->live) (void)hipFree(kv.first);  // leaked by the caller
   delete pool_of(ctx);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+  }
+  if (ctx->pinned) {
+    auto* m = static_cast<std::unordered_map<void*, size_t>*>(ctx->pinned);
+    for (auto& kv : *m) (void)hipHostFree(kv.first);  // leaked by the caller
+    delete m;
+  }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return I8IE_OK;
@@ -220,6 +229,7 @@ int i8ie_profile_start(i8ie_ctx* ctx, int mfma_kernels_only) {
   if (!ctx->prof) ctx->prof = new (std::nothrow) I8ieProf();
   I8IE_REQUIRE(ctx->prof != nullptr, "out of host memory");
   ctx->prof_mfma_only = mfma_kernels_only ? 1 : 0;
+  ctx->prof_seen = 0;
   return I8IE_OK;
 }
 
@@ -283,6 +293,155 @@ int i8ie_memcpy_d2d(i8ie_ctx* ctx, void* dst_dev, const void* src_dev, size_t by
   I8IE_REQUIRE(dst_dev != nullptr && src_dev != nullptr, "null pointer");
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
   I8IE_HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return I8IE_OK;
+}
+
+// ---- asynchronous transfers: pinned host blocks, a transfer stream, events -------------------
+struct i8ie_event {
+  hipEvent_t ev;
+  int device;
+};
+
+static std::unordered_map<void*, size_t>* pinned_of(i8ie_ctx* ctx) {
+  if (!ctx->pinned) ctx->pinned = new std::unordered_map<void*, size_t>();
+  return static_cast<std::unordered_map<void*, size_t>*>(ctx->pinned);
+}
+// the block [p, p+bytes) lies inside one i8ie_host_malloc allocation of this ctx
+static bool is_pinned(i8ie_ctx* ctx, const void* p, size_t bytes) {
+  if (!ctx->pinned) return false;
+  for (auto& kv : *pinned_of(ctx)) {
+    const char* base = static_cast<const char*>(kv.first);
+    const char* q = static_cast<const char*>(p);
+    if (q >= base && q + bytes <= base + kv.second) return true;
+  }
+  return false;
+}
+static int stream_for(i8ie_ctx* ctx, int on_copy_stream, hipStream_t* out) {
+  if (!on_copy_stream) {
+    *out = ctx->stream;
+    return I8IE_OK;
+  }
+  if (!ctx->copy_stream) I8IE_HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  *out = ctx->copy_stream;
+  return I8IE_OK;
+}
+
+int i8ie_host_malloc(i8ie_ctx* ctx, size_t bytes, void** host) {
+  I8IE_REQUIRE(ctx != nullptr && host != nullptr, "null argument");
+  *host = nullptr;
+  if (bytes == 0) return I8IE_OK;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    i8ie_set_error("hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? I8IE_ERR_OOM : I8IE_ERR_HIP;
+  }
+  (*pinned_of(ctx))[p] = bytes;
+  *host = p;
+  return I8IE_OK;
+}
+
+int i8ie_host_free(i8ie_ctx* ctx, void* host) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  if (!host) return I8IE_OK;
+  auto* m = pinned_of(ctx);
+  auto it = m->find(host);
+  I8IE_REQUIRE(it != m->end(), "i8ie_host_free: not a block of i8ie_host_malloc");
+  m->erase(it);
+  I8IE_HIP_TRY(hipHostFree(host));  // waits for transfers that still use the block
+  return I8IE_OK;
+}
+
+int i8ie_host_is_pinned(i8ie_ctx* ctx, const void* p, size_t bytes, int* yes) {
+  I8IE_REQUIRE(ctx != nullptr && yes != nullptr, "null argument");
+  *yes = (p != nullptr && is_pinned(ctx, p, bytes)) ? 1 : 0;
+  return I8IE_OK;
+}
+
+int i8ie_memcpy_h2d_async(i8ie_ctx* ctx, void* dst_dev, const void* src_pinned, size_t bytes, int on_copy_stream) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  if (bytes == 0) return I8IE_OK;
+  I8IE_REQUIRE(dst_dev != nullptr && src_pinned != nullptr, "null pointer");
+  I8IE_REQUIRE(is_pinned(ctx, src_pinned, bytes), "i8ie_memcpy_h2d_async: source is not i8ie_host_malloc memory");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s;
+  if (int rc = stream_for(ctx, on_copy_stream, &s)) return rc;
+  I8IE_HIP_TRY(hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, s));
+  return I8IE_OK;
+}
+
+int i8ie_memcpy_d2h_async(i8ie_ctx* ctx, void* dst_pinned, const void* src_dev, size_t bytes, int on_copy_stream) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  if (bytes == 0) return I8IE_OK;
+  I8IE_REQUIRE(dst_pinned != nullptr && src_dev != nullptr, "null pointer");
+  I8IE_REQUIRE(is_pinned(ctx, dst_pinned, bytes), "i8ie_memcpy_d2h_async: destination is not i8ie_host_malloc memory");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s;
+  if (int rc = stream_for(ctx, on_copy_stream, &s)) return rc;
+  I8IE_HIP_TRY(hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s));
+  return I8IE_OK;
+}
+
+int i8ie_event_create(i8ie_ctx* ctx, i8ie_event** out) {
+  I8IE_REQUIRE(ctx != nullptr && out != nullptr, "null argument");
+  *out = nullptr;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  i8ie_event* e = new (std::nothrow) i8ie_event();
+  if (!e) return I8IE_ERR_OOM;
+  e->device = ctx->device;
+  hipError_t rc = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+  if (rc != hipSuccess) {
+    delete e;
+    i8ie_set_error("hipEventCreate: %s", hipGetErrorString(rc));
+    return I8IE_ERR_HIP;
+  }
+  *out = e;
+  return I8IE_OK;
+}
+
+int i8ie_event_record(i8ie_ctx* ctx, i8ie_event* ev, int on_copy_stream) {
+  I8IE_REQUIRE(ctx != nullptr && ev != nullptr, "null argument");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s;
+  if (int rc = stream_for(ctx, on_copy_stream, &s)) return rc;
+  I8IE_HIP_TRY(hipEventRecord(ev->ev, s));
+  return I8IE_OK;
+}
+
+int i8ie_stream_wait_event(i8ie_ctx* ctx, i8ie_event* ev, int copy_stream_waits) {
+  I8IE_REQUIRE(ctx != nullptr && ev != nullptr, "null argument");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s;
+  if (int rc = stream_for(ctx, copy_stream_waits, &s)) return rc;
+  I8IE_HIP_TRY(hipStreamWaitEvent(s, ev->ev, 0));
+  return I8IE_OK;
+}
+
+int i8ie_event_synchronize(i8ie_event* ev) {
+  I8IE_REQUIRE(ev != nullptr, "null event");
+  I8IE_HIP_TRY(hipSetDevice(ev->device));
+  I8IE_HIP_TRY(hipEventSynchronize(ev->ev));
+  return I8IE_OK;
+}
+
+int i8ie_event_query(i8ie_event* ev, int* done) {
+  I8IE_REQUIRE(ev != nullptr && done != nullptr, "null argument");
+  I8IE_HIP_TRY(hipSetDevice(ev->device));
+  hipError_t rc = hipEventQuery(ev->ev);
+  if (rc != hipSuccess && rc != hipErrorNotReady) {
+    i8ie_set_error("hipEventQuery: %s", hipGetErrorString(rc));
+    return I8IE_ERR_HIP;
+  }
+  *done = rc == hipSuccess;
+  return I8IE_OK;
+}
+
+int i8ie_event_destroy(i8ie_event* ev) {
+  if (!ev) return I8IE_OK;
+  (void)hipSetDevice(ev->device);
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
   return I8IE_OK;
 }
 

@@ -19,6 +19,10 @@ struct i8ie_ctx {
   unsigned options = 0;  // bit 0: I8IE_OPT_FORCE_FALLBACK
   int variant = 0;  // I8IE_OPT_KERNEL_VARIANT: selects among compiled kernel variants (A/B timing aid)
   int prof_mfma_only = 0;  // time only the contraction kernels (fewer event packets in a timed region)
+  int prof_stride = 1;     // I8IE_OPT_PROFILE_STRIDE: bracket every prof_stride-th eligible launch
+  unsigned prof_seen = 0;  // eligible launches since i8ie_profile_start
+  hipStream_t copy_stream = nullptr;  // transfer stream for the *_async copies (created on first use)
+  void* pinned = nullptr;  // std::unordered_map<void*, size_t>* of i8ie_host_malloc blocks
 };
 
 // Per-launch HIP-event timing on the ctx's stream (off unless i8ie_profile_start was
@@ -29,6 +33,7 @@ struct I8ieProfScope {
   i8ie_ctx* c;
   I8ieProfScope(i8ie_ctx* ctx, const char* name, double ops, double bytes) : c(ctx) {
     on = c->prof != nullptr && (!c->prof_mfma_only || ops > 0.0);
+    if (on && c->prof_stride > 1) on = (c->prof_seen++ % (unsigned)c->prof_stride) == 0;
     if (on) i8ie_prof_begin(c, name, ops, bytes);
   }
   ~I8ieProfScope() {

@@ -89,9 +89,63 @@ std::map<BorderKey, std::vector<void*>>& border_cache() {
   return *m;
 }
 
+// ---- pinned host staging, events and upload blocks (asynchronous transfers) ----
+struct PinnedPool {
+  std::map<size_t, std::vector<void*>> free_blocks;  // by capacity (multiples of 4 KiB)
+  std::vector<i8ie_event*> events;
+  size_t user_blocks = 0;  // live pinned_empty() arrays
+};
+PinnedPool& ppool() {
+  static auto* p = new PinnedPool();
+  return *p;
+}
+size_t pinned_capacity(size_t bytes) { return (bytes + 4095) & ~(size_t)4095; }
+void* pinned_take(size_t cap) {
+  auto& v = ppool().free_blocks[cap];
+  if (!v.empty()) {
+    void* p = v.back();
+    v.pop_back();
+    return p;
+  }
+  void* p = nullptr;
+  check(i8ie_host_malloc(ctx(), cap, &p));
+  return p;
+}
+void pinned_put(void* p, size_t cap) {
+  auto& v = ppool().free_blocks[cap];
+  if (v.size() < 8) v.push_back(p);
+  else i8ie_host_free(ctx(), p);
+}
+i8ie_event* event_take() {
+  auto& v = ppool().events;
+  if (!v.empty()) {
+    i8ie_event* e = v.back();
+    v.pop_back();
+    return e;
+  }
+  i8ie_event* e = nullptr;
+  check(i8ie_event_create(ctx(), &e));
+  return e;
+}
+void event_put(i8ie_event* e) { ppool().events.push_back(e); }
+// Device blocks written by the transfer stream.  They bypass the stream-ordered allocator (whose reuse
+// rule only covers the compute stream): a block comes back with an event recorded behind its last
+// compute-stream reader, and the next upload into it makes the transfer stream wait for that event.
+struct UploadSlot {
+  void* dev;
+  i8ie_event* free_ev;
+};
+std::map<size_t, std::vector<UploadSlot>>& upload_cache() {
+  static auto* m = new std::map<size_t, std::vector<UploadSlot>>();
+  return *m;
+}
+
 struct Storage {
   size_t bytes = 0;
   void* dev = nullptr;
+  i8ie_event* ready_ev = nullptr;  // recorded on the transfer stream behind the upload into `dev`
+  bool upload_block = false;       // `dev` belongs to upload_cache()
+  py::object keep;                 // the pinned ndarray an asynchronous upload reads from
   int bzp = -1;  // >= 0: bordered NHWC buffer with border bytes == bzp (returns to border_cache)
   std::vector<unsigned char> host;
   bool host_valid = false;
@@ -118,8 +172,37 @@ struct Storage {
     border = 0;
     bzp = -1;
   }
+  void wait_upload_on_stream() {  // the compute stream waits (device side) for the upload
+    if (!ready_ev) return;
+    check(i8ie_stream_wait_event(ctx(), ready_ev, 0));
+    event_put(ready_ev);
+    ready_ev = nullptr;
+    keep = py::object();
+  }
+  void wait_upload_on_host() {
+    if (!ready_ev) return;
+    {
+      py::gil_scoped_release nogil;
+      check(i8ie_event_synchronize(ready_ev));
+    }
+    keep = py::object();  // the source may be refilled; the compute stream still has to wait on the event
+  }
   ~Storage() {
     if (!dev || !rt().ctx) return;
+    if (ready_ev) {  // never consumed: let the copy finish before the block is reused
+      i8ie_stream_wait_event(rt().ctx, ready_ev, 0);
+      event_put(ready_ev);
+      ready_ev = nullptr;
+    }
+    if (upload_block) {
+      auto& slot = upload_cache()[bytes];
+      if (slot.size() < 4) {
+        i8ie_event* e = event_take();
+        i8ie_event_record(rt().ctx, e, 0);
+        slot.push_back(UploadSlot{dev, e});
+        return;
+      }
+    }
     if (bzp >= 0 && layout == I8IE_LAYOUT_NHWC && border > 0) {
       auto& slot = border_cache()[BorderKey{bytes, dn, dc, dh, dw, border, bzp}];
       if (slot.size() < 4) {
@@ -130,6 +213,7 @@ struct Storage {
     i8ie_free(rt().ctx, dev);
   }
   void* device_ptr() {
+    if (ready_ev) wait_upload_on_stream();
     if (!dev) {
       check(i8ie_malloc(ctx(), bytes, &dev));
       if (host_valid) {
@@ -144,6 +228,7 @@ struct Storage {
     return dev;
   }
   void read_back(void* dst) {
+    if (ready_ev) wait_upload_on_stream();
     if (host_valid) {
       std::memcpy(dst, host.data(), bytes);
       return;
@@ -234,6 +319,8 @@ struct Tensor {
     }
     return out;
   }
+  struct HostFuture;
+  std::shared_ptr<HostFuture> numpy_async();
   // include/tensor.h:106-133: at most one -1, no zeros, sizes must match
   Tensor<T> reshape(std::vector<ssize_t> shp) {
     realize();
@@ -265,12 +352,119 @@ struct Tensor {
   }
 };
 
+// numpy() split in two: the device->host copy is queued behind the tensor's kernels into pinned staging
+// memory and result() waits for it, so the caller can launch the next batch in between.
+template <typename T>
+struct Tensor<T>::HostFuture {
+  std::vector<ssize_t> shape;
+  size_t bytes = 0, cap = 0;
+  void* buf = nullptr;
+  i8ie_event* ev = nullptr;
+  py::object ready;  // already on the host
+  HostFuture() = default;
+  HostFuture(const HostFuture&) = delete;
+  HostFuture& operator=(const HostFuture&) = delete;
+  bool done() {
+    if (!ev) return true;
+    int d = 0;
+    check(i8ie_event_query(ev, &d));
+    return d != 0;
+  }
+  py::object result() {
+    if (ready) return ready;
+    if (ev) {
+      py::gil_scoped_release nogil;
+      check(i8ie_event_synchronize(ev));
+    }
+    py::array_t<T> out(shape);
+    if (bytes) std::memcpy(out.mutable_data(), buf, bytes);
+    release();
+    ready = out;
+    return ready;
+  }
+  void release() {
+    if (ev) event_put(ev);
+    if (buf) pinned_put(buf, cap);
+    ev = nullptr;
+    buf = nullptr;
+  }
+  ~HostFuture() {
+    if (!rt().ctx) return;
+    if (ev) i8ie_event_synchronize(ev);  // the copy may still be writing the staging block
+    release();
+  }
+};
+template <typename T>
+std::shared_ptr<typename Tensor<T>::HostFuture> Tensor<T>::numpy_async() {
+  realize();
+  auto f = std::make_shared<HostFuture>();
+  f->shape = shape;
+  if (!st || size == 0 || st->host_valid) {
+    f->ready = numpy();
+    return f;
+  }
+  st->to_nchw();
+  f->bytes = (size_t)size * sizeof(T);
+  f->cap = pinned_capacity(f->bytes);
+  f->buf = pinned_take(f->cap);
+  check(i8ie_memcpy_d2h_async(ctx(), f->buf, st->device_ptr(), f->bytes, 0));
+  f->ev = event_take();
+  check(i8ie_event_record(ctx(), f->ev, 0));
+  return f;
+}
+
+// float32 ndarray in pinned host memory: i8ie.tensor() of it (or of a slice of it) uploads asynchronously
+py::array_t<float> pinned_empty(std::vector<ssize_t> shape) {
+  size_t n = 1;
+  for (ssize_t d : shape) {
+    if (d < 0) throw std::runtime_error("i8ie: pinned_empty: negative dimension");
+    n *= (size_t)d;
+  }
+  void* p = nullptr;
+  check(i8ie_host_malloc(ctx(), std::max<size_t>(n * sizeof(float), 4), &p));
+  ppool().user_blocks += 1;
+  py::capsule owner(p, [](void* q) {
+    if (rt().ctx) i8ie_host_free(rt().ctx, q);
+    ppool().user_blocks -= 1;
+  });
+  return py::array_t<float>(shape, static_cast<float*>(p), owner);
+}
+
 Tensor<float> tensor_from_numpy(py::array_t<float, py::array::c_style | py::array::forcecast> a) {
   Tensor<float> t;  // include/tensor.h:40-47: copies the ndarray
   t.shape.assign(a.shape(), a.shape() + a.ndim());
   t.size = a.size();
   t.st = std::make_shared<Storage>();
   t.st->bytes = (size_t)t.size * sizeof(float);
+  int pinned = 0;
+  if (ppool().user_blocks > 0 && t.st->bytes > 0)
+    check(i8ie_host_is_pinned(ctx(), a.data(), t.st->bytes, &pinned));
+  if (pinned) {
+    // The copy the reference makes at construction becomes an asynchronous upload on the transfer
+    // stream; the ndarray must stay unchanged until wait_upload() (or the first read-back) returns.
+    Storage& st = *t.st;
+    auto& uc = upload_cache()[st.bytes];
+    if (!uc.empty()) {
+      UploadSlot slot = uc.back();
+      uc.pop_back();
+      check(i8ie_stream_wait_event(ctx(), slot.free_ev, 1));
+      event_put(slot.free_ev);
+      st.dev = slot.dev;
+    } else {
+      check(i8ie_malloc(ctx(), st.bytes, &st.dev));
+      // a block fresh from the allocator may still be read by queued compute-stream work
+      i8ie_event* e = event_take();
+      check(i8ie_event_record(ctx(), e, 0));
+      check(i8ie_stream_wait_event(ctx(), e, 1));
+      event_put(e);
+    }
+    st.upload_block = true;
+    st.keep = a;
+    check(i8ie_memcpy_h2d_async(ctx(), st.dev, a.data(), st.bytes, 1));
+    st.ready_ev = event_take();
+    check(i8ie_event_record(ctx(), st.ready_ev, 1));
+    return t;
+  }
   t.st->host.resize(t.st->bytes);
   if (t.st->bytes) std::memcpy(t.st->host.data(), a.data(), t.st->bytes);
   t.st->host_valid = true;
@@ -279,9 +473,15 @@ Tensor<float> tensor_from_numpy(py::array_t<float, py::array::c_style | py::arra
 
 template <typename T>
 void bind_tensor(py::module_& m, const char* name) {
+  using Fut = typename Tensor<T>::HostFuture;
+  py::class_<Fut, std::shared_ptr<Fut>>(m, (std::string(name) + "_HostFuture").c_str())
+      .def("done", &Fut::done)
+      .def("result", &Fut::result);
   py::class_<Tensor<T>>(m, name)
       .def(py::init<>())
       .def("numpy", &Tensor<T>::numpy)
+      .def("numpy_async", &Tensor<T>::numpy_async)
+      .def("wait_upload", [](Tensor<T>& t) { if (t.st) t.st->wait_upload_on_host(); })
       .def("zero_point", [](const Tensor<T>& t) { return t.zero_point; })
       .def("scale", [](const Tensor<T>& t) { return t.scale; })
       .def("sum",
@@ -858,15 +1058,30 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
     check(i8ie_memory_stats(ctx(), &live, &cached, &allocs));
     return py::make_tuple(live, cached, allocs);
   });
+  m.def("pinned_empty", &pinned_empty);
   m.def("trim", []() {
     for (auto& kv : border_cache())
       for (void* p : kv.second) i8ie_free(ctx(), p);
     border_cache().clear();
+    for (auto& kv : upload_cache())
+      for (UploadSlot& u : kv.second) {
+        check(i8ie_stream_wait_event(ctx(), u.free_ev, 0));  // order the reuse behind the recorded reader
+        event_put(u.free_ev);
+        i8ie_free(ctx(), u.dev);
+      }
+    upload_cache().clear();
+    for (auto& kv : ppool().free_blocks)
+      for (void* p : kv.second) i8ie_host_free(ctx(), p);
+    ppool().free_blocks.clear();
     check(i8ie_trim(ctx()));
   });
   m.def("force_fallback", [](bool on) { check(i8ie_ctx_set_option(ctx(), I8IE_OPT_FORCE_FALLBACK, on ? 1 : 0)); });
-  m.def("profile_start", [](bool mfma_only) { check(i8ie_profile_start(ctx(), mfma_only ? 1 : 0)); },
-        py::arg("mfma_only") = false);
+  m.def("profile_start",
+        [](bool mfma_only, int stride) {
+          check(i8ie_ctx_set_option(ctx(), I8IE_OPT_PROFILE_STRIDE, stride));
+          check(i8ie_profile_start(ctx(), mfma_only ? 1 : 0));
+        },
+        py::arg("mfma_only") = false, py::arg("stride") = 1);
   m.def("profile_stop", []() {
     std::vector<i8ie_profile_entry> e(64);
     int n = 0;

@@ -16,7 +16,7 @@ FullyConnected = Linear  # BASELINE.json's name for the same class (no such symb
 __all__ = [
     "tensor", "argmax", "relu", "max_pool2d", "quantize", "dequantize",
     "Linear", "FullyConnected", "Conv2d", "Tensor", "Module",
-    "synchronize", "set_device",
+    "synchronize", "set_device", "pinned_empty",
 ]
 
 
@@ -50,6 +50,13 @@ def dequantize(x):
 def synchronize():
     """Wait for all queued device work (ops are asynchronous on one HIP stream)."""
     _C.synchronize()
+
+
+def pinned_empty(shape):
+    """float32 ndarray in pinned host memory.  `tensor()` of it (or of a contiguous slice) uploads on
+    the transfer stream, beside the kernels of the batch before; keep the contents unchanged until
+    `Tensor.wait_upload()` returns."""
+    return _C.pinned_empty([int(d) for d in shape])
 
 
 def set_device(index):

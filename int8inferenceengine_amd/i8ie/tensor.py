@@ -47,6 +47,17 @@ class Tensor:
         self.data.prefetch()
         return self
 
+    def numpy_async(self):
+        """Additive: queue the device -> host copy behind this tensor's kernels and return a future
+        (`.result()` -> ndarray, `.done()`), so the next batch can be launched before the wait."""
+        return self.data.numpy_async()
+
+    def wait_upload(self):
+        """Additive: block until an asynchronous upload from a `pinned_empty` array has finished
+        (after this the source array may be refilled)."""
+        self.data.wait_upload()
+        return self
+
     def __eq__(self, other):
         # element-wise equality as a float tensor (reference :11-12); NOT wrapped in Tensor there either
         return _C.tensor(self.numpy() == other.numpy())

@@ -10,6 +10,9 @@
 //   mode 7: staging by LDS-DMA: 8 x global_load_lds_dwordx4 per thread per tile (L2-resident source),
 //           issued before the MFMAs, vmcnt(0) + barrier after them; no ds_write at all
 //   mode 8: as 7 with the DMA issue spread over the k-steps (2 per k-step)
+//   mode 9: B fragments straight from a fragment-ordered global panel (1 KiB coalesced per wave-load,
+//           L2/L1 resident, loaded one tile ahead), A through LDS: 2 A-fragment reads per k-step,
+//           4 ds_write_b128 per thread per tile, one barrier
 // build: hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -33,10 +36,45 @@ __global__ __launch_bounds__(256) void k(int iters, int* out, const unsigned cha
   const int wr = (tid >> 3) * 144 + (tid & 7) * 16;
   v4i st[8];
   for (int i = 0; i < 8; ++i) st[i] = v4i{tid + i, i, 3, 4};
+  v4i bq[2][2][4];  // mode 9: [parity][n-tile][k-step]
+  if (MODE == 9) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        bq[0][n][ks] = *reinterpret_cast<const v4i*>(gsrc + (size_t)(blockIdx.x & 255) * 65536 + ((wn * 2 + n) * 4 + ks) * 1024 + lane * 16);
+  }
   v4i a2[2], b2[2];
   // DMA: lane's global source (1 KiB per wave-instruction, 16 B per lane), L2-resident 64 KiB window per block
   const unsigned char* gp = gsrc + (size_t)(blockIdx.x & 255) * 65536 + tid * 16;
   for (int it = 0; it < iters; ++it) {
+    if (MODE == 9) {
+      // static register parity: two tiles per loop trip
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const unsigned char* nb = gsrc + (size_t)(blockIdx.x & 255) * 65536 + (((it + par + 1) & 3) * 16384);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            bq[par ^ 1][n][ks] = *reinterpret_cast<const v4i*>(nb + ((wn * 2 + n) * 4 + ks) * 1024 + lane * 16);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) a[m] = *reinterpret_cast<const v4i*>(smem + ks * 32 + ard[m]);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[par][n][ks], a[m], acc[m][n], 0, 0, 0);
+          *reinterpret_cast<v4i*>(smem + 256 * 144 + wr + ks * 32 * 144) = st[ks] ^ (int)0x80808080;
+        }
+        __syncthreads();
+      }
+      st[it & 3].x += acc[0][0][0];
+      ++it;
+      continue;
+    }
     if (MODE == 7) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -134,6 +172,7 @@ int main() {
     run<6>("spread writes + frag dbuf", b);
     run<7>("LDS-DMA staging, up front", b);
     run<8>("LDS-DMA staging, spread", b);
+    run<9>("B direct from global, A via LDS", b);
   }
   return 0;
 }
