@@ -2,6 +2,7 @@
 // Replaces the reference's host-side `new T[]` + py::capsule ownership
 // (include/tensor.h:26-61) with explicit device allocations on one HIP stream.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -107,6 +108,7 @@ static int ctx_make(int device, hipStream_t borrowed, bool borrow, i8ie_ctx** ou
     return I8IE_ERR_OOM;
   }
   c->device = device;
+  if (const char* e = std::getenv("I8IE_KERNEL_VARIANT")) c->variant = std::atoi(e);  // A/B aid, see I8IE_OPT_KERNEL_VARIANT
   if (borrow) {
     c->stream = borrowed;
     c->own_stream = false;

@@ -110,18 +110,33 @@ struct IgemmArgs {
 
 // VAR (tuning variants, identical results): 0 = two LDS stages, loads one K tile ahead;
 // 1 = loads two K tiles ahead (second register set); 2 = VAR 0 + s_setprio around the MFMAs;
-// 3 = one LDS stage, two barriers per K tile (half the LDS: more blocks per CU)
+// 3 = one LDS stage, two barriers per K tile (half the LDS: more blocks per CU);
+// 5 = VAR 3 staged by LDS-DMA (buffer_load ... lds, 1 KiB per wave-instruction, no VGPR pass, no ds_write):
+//     unpadded 128-B LDS rows, 16-B chunk c of row r stored at chunk c ^ (r & 7) (conflict-free
+//     ds_read_b128 fragments), the u8 -> s8 re-bias applied to the A fragments after the read;
+// 7 = the DMA form with two 64 KiB stages in dynamic LDS (one block per CU): the fill of K tile k+1 is in
+//     flight under the MFMAs of K tile k, one barrier per K tile.  Meant for 256 x 256 / 256 x 192 block
+//     tiles (4 waves of 128 x 128 / 128 x 96): twice the MFMA work per staged byte, which is what the
+//     fill latency x LDS capacity product allows to keep the matrix cores busy
+extern __shared__ __attribute__((aligned(16))) uint8_t i8ie_dyn_smem[];
+
 template <int AMODE, int WM, int WN, int TM, int TN, bool BIAS, bool ACC, int VAR>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, int tiles_m, int tiles_n,
                                                                  int m_fastest) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
-  constexpr int NST = VAR == 3 ? 1 : 2;
+  constexpr bool DMA2 = VAR == 7;
+  constexpr bool DMA = VAR == 5 || DMA2;
+  constexpr int NST = (VAR == 3 || VAR == 5) ? 1 : 2;
   constexpr int A_PER = BM * 8 / NT, B_PER = BN * 8 / NT;
   static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "staging map");
-  constexpr int STAGE = (BM + BN) * LROW;
+  static_assert(!DMA || NT % 64 == 0, "DMA rows per pass are a multiple of 8");
+  constexpr int LR = DMA ? BK2 : LROW;  // LDS row pitch
+  constexpr int STAGE = DMA2 ? 65536 : (BM + BN) * LR;  // DMA2: power-of-two pitch, stages toggle by XOR
+  static_assert((BM + BN) * LR <= STAGE, "stage holds the A and B tiles");
   constexpr int SROW = BN + 4;  // epilogue tile row stride: odd dword count -> conflict-free ds_write_b32
   static_assert(BM * SROW <= NST * STAGE, "epilogue tile fits");
-  __shared__ __attribute__((aligned(16))) uint8_t smem[NST * STAGE];
+  __shared__ __attribute__((aligned(16))) uint8_t smem_static[DMA2 ? 16 : NST * STAGE];
+  uint8_t* const smem = DMA2 ? i8ie_dyn_smem : smem_static;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -142,26 +157,24 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
 
   // ---- accumulators: D = W_tile x A_tile^T; lane & 31 -> activation row,
   //      feature = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // start at zero; oc'[j] = oc[j] + 128 * wsum[j] joins in the epilogue (integer adds commute exactly), which
+  // keeps global loads and their latency out of the prologue
   v16i acc[TM][TN];
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const int nb = n0 + (wn * TN + ni) * 32 + 4 * (lane >> 5);
+  for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int gcol = nb + (r & 3) + 8 * (r >> 2);
-      // (unconditional loads here make hipcc double the AGPRs); K slices > 0 of a split-K launch start at 0
-      const int init = (gcol < p.N && blockIdx.y == 0) ? p.ocp[gcol] : 0;
+    for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi) acc[mi][ni][r] = init;
-    }
-  }
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0;
 
   // ---- staging state ------------------------------------------------------------------
   const __amdgpu_buffer_rsrc_t rsA =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.A), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.B), 0, p.b_bytes, 0x00020000);
-  const int cA = tid & 7;
+  // K chunk (16 B) this thread stages for each of its rows; with DMA the lane's LDS slot is fixed
+  // (slot = lane), so the swizzle picks the source chunk instead: c = slot ^ (row & 7)
+  const int cA = DMA ? ((tid & 7) ^ ((tid >> 3) & 7)) : (tid & 7);
   unsigned a_off[A_PER], b_off[B_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) {
     const int idx = tid + i * NT;
-    b_off[i] = (unsigned)(n0 + (idx >> 3)) * (unsigned)p.Kpad + (idx & 7) * 16;
+    b_off[i] = (unsigned)(n0 + (idx >> 3)) * (unsigned)p.Kpad + (DMA ? cA : (idx & 7)) * 16;
   }
   // this thread's K chunk q = cA, cA + 8, ...: byte offset inside the window
   unsigned koff;
@@ -212,7 +225,38 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
     }
   };
   auto load_tile = [&](int k0) { load_into(k0, ra, rb); };
-
+  // LDS-DMA: wave-instruction i of wave w fills LDS granules [i * NT + 64 w, + 64) = 8 rows x 128 B
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // quarter q of the fill of one K tile (the fill is spread over the four k-steps of the tile before)
+  auto dma_part = [&](int k0, int stage_off, int q) {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i)
+      if (i * 4 / A_PER == q || (A_PER < 4 && q == 0))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsA, (__attribute__((address_space(3))) void*)(smem + stage_off + (i * NT + wave_u * 64) * 16), 16,
+            (int)(a_off[i] + koff), 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i)
+      if (i * 4 / B_PER == q || (B_PER < 4 && q == 0))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsB, (__attribute__((address_space(3))) void*)(smem + stage_off + BM * LR + (i * NT + wave_u * 64) * 16),
+            16, (int)b_off[i], k0 + kbase_l, 0, 0);
+  };
+  auto dma_advance = [&]() {
+    koff += BK2;
+    if (AMODE == 1) {
+      f += 8;
+      while (f >= p.RC) {
+        f -= p.RC;
+        koff += p.row_jump;
+      }
+    }
+  };
+  auto dma_tile = [&](int k0, int stage_off) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma_part(k0, stage_off, q);
+    dma_advance();
+  };
   // LDS addresses (bytes from smem); stage s adds s * STAGE as an immediate
   int a_wr[A_PER], b_wr[B_PER], a_rd[TM], b_rd[TN];
 #pragma unroll
@@ -237,6 +281,43 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
     for (int i = 0; i < B_PER; ++i) *reinterpret_cast<v4i*>(smem + S * STAGE + b_wr[i]) = sb[i];
   };
   auto store_tile = [&](auto sc) { store_from(sc, ra, rb); };
+  // DMA image: fragment of k-step ks for row r sits at chunk (2 ks + (lane >> 5)) ^ (r & 7); r & 7 == lane & 7
+  int a_rdk[DMA ? 4 : 1], b_rdk[DMA ? 4 : 1];
+  if (DMA) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int sw = ((ks * 2 + (lane >> 5)) ^ (lane & 7)) * 16;
+      a_rdk[ks] = (wm * TM * 32 + (lane & 31)) * LR + sw;
+      b_rdk[ks] = BM * LR + (wn * TN * 32 + (lane & 31)) * LR + sw;
+    }
+  }
+  auto compute_dma = [&](bool fill_next, int k0, int stage_off) {
+    v4i af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) af[0][mi] = *reinterpret_cast<const v4i*>(smem + a_rdk[0] + mi * 32 * LR);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) bf[0][ni] = *reinterpret_cast<const v4i*>(smem + b_rdk[0] + ni * 32 * LR);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+          af[(ks + 1) & 1][mi] = *reinterpret_cast<const v4i*>(smem + a_rdk[ks + 1] + mi * 32 * LR);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          bf[(ks + 1) & 1][ni] = *reinterpret_cast<const v4i*>(smem + b_rdk[ks + 1] + ni * 32 * LR);
+      }
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const v4i as8 = af[ks & 1][mi] ^ (int)0x80808080;  // u8 -> s8
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ks & 1][ni], as8, acc[mi][ni], 0, 0, 0);
+      }
+      if (DMA2 && fill_next) dma_part(k0, stage_off, ks);  // a quarter of the next tile's fill per k-step
+    }
+    if (DMA2 && fill_next) dma_advance();
+  };
   auto compute = [&](auto sc) {
     constexpr int S = decltype(sc)::value;
     v4i af[2][TM], bf[2][TN];  // fragments of k-step ks+1 are fetched under the MFMAs of k-step ks
@@ -276,7 +357,36 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
     koff += kbase;
     kbase_l = kbase;
   }
-  if constexpr (VAR == 3) {  // one stage: compute | barrier | refill | barrier
+  if constexpr (DMA2) {  // two stages: fill of tile k+1 in flight under the MFMAs of tile k, one barrier per tile
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int fill = STAGE;  // byte offset of the stage the next fill goes to
+    for (int kt = 0; kt < nk; ++kt) {
+      compute_dma(kt + 1 < nk, (kt + 1) * BK2, fill);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {  // fragments of the next tile come from the other stage
+        a_rdk[ks] ^= STAGE;
+        b_rdk[ks] ^= STAGE;
+      }
+      fill ^= STAGE;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else if constexpr (DMA) {  // one stage: DMA fill | wait + barrier | compute | barrier
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      compute_dma(false, 0, 0);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        dma_tile((kt + 1) * BK2, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
+  } else if constexpr (VAR == 3) {  // one stage: compute | barrier | refill | barrier
     load_tile(0);
     store_tile(S0{});
     __syncthreads();
@@ -332,7 +442,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int gcol = n0 + (wn * TN + ni) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (grow < p.M && gcol < p.N) slab[(size_t)grow * p.N + gcol] = acc[mi][ni][r];
+          if (grow < p.M && gcol < p.N)
+            slab[(size_t)grow * p.N + gcol] = acc[mi][ni][r] + (blockIdx.y == 0 ? p.ocp[gcol] : 0);
         }
       }
     return;
@@ -349,14 +460,16 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
       const int lcol0 = (wn * TN + ni) * 32 + 8 * g + 4 * (lane >> 5);
       const int gcol0 = n0 + lcol0;
       float4 bfv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (BIAS) bfv = *reinterpret_cast<const float4*>(p.biasf + gcol0);  // padded to Npad
+      if (BIAS && gcol0 < p.N) bfv = *reinterpret_cast<const float4*>(p.biasf + gcol0);  // padded to Npad
+      // (feature tiles wider than 128 may run past Npad: columns >= N are never stored)
+      const int4 ocv = gcol0 < p.N ? *reinterpret_cast<const int4*>(p.ocp + gcol0) : make_int4(0, 0, 0, 0);
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
         const int lrow = (wm * TM + mi) * 32 + (lane & 31);
         int cv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          int c = acc[mi][ni][g * 4 + r];
+          int c = acc[mi][ni][g * 4 + r] + (r == 0 ? ocv.x : r == 1 ? ocv.y : r == 2 ? ocv.z : ocv.w);
           if (ACC) {
             const int grow = m0 + lrow, gcol = gcol0 + r;
             if (grow < p.M && gcol < p.N) p.acc[(size_t)grow * p.N + gcol] = c;
@@ -612,9 +725,19 @@ int launch_cfg(i8ie_ctx* ctx, const IgemmArgs& a, const char* name, int kbytes, 
   char tag[64];
   snprintf(tag, sizeof(tag), "%s|M%d,N%d,K%d", name, a.M, a.N, kbytes);
   I8ieProfScope prof(ctx, ctx->prof ? tag : name, ops, bytes);
+  constexpr unsigned dyn_lds = VAR == 7 ? 2u * 65536u : 0u;
+  if (VAR == 7) {
+    static bool raised = false;  // per instantiation: allow 128 KiB of dynamic LDS
+    if (!raised) {
+      I8IE_HIP_TRY(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&igemm_u8s8_kernel<AMODE, WM, WN, TM, TN, BIAS, ACC, VAR>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+      raised = true;
+    }
+  }
   igemm_u8s8_kernel<AMODE, WM, WN, TM, TN, BIAS, ACC, VAR>
-      <<<dim3(tiles_m * tiles_n, a.ksplit > 1 ? a.ksplit : 1), WM * WN * 64, 0, ctx->stream>>>(a, tiles_m, tiles_n,
-                                                                                             m_fastest);
+      <<<dim3(tiles_m * tiles_n, a.ksplit > 1 ? a.ksplit : 1), WM * WN * 64, dyn_lds, ctx->stream>>>(
+          a, tiles_m, tiles_n, m_fastest);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }
@@ -642,9 +765,11 @@ int launch_tile_var(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, d
                                                        ops, bytes);
 }
 
-// Default: one LDS stage (VAR 3).  Measured on MI355X (tools/bench_layer.py, AlexNet conv2-5): half the
-// LDS lets a third wave per SIMD in, +10 % over the two-stage form; loads two tiles ahead and
-// s_setprio around the MFMAs measured within 2 % of the baseline.  ctx->variant selects the others.
+// Default: one LDS stage filled by LDS-DMA (VAR 5).  Measured on MI355X (tools/bench_layer.py, AlexNet
+// conv2-5): one stage (half the LDS) lets a third wave per SIMD in, +10 % over the two-stage form; DMA
+// staging +3-6 % over register staging (VAR 3); loads two tiles ahead and s_setprio around the MFMAs
+// within 2 % of the baseline; the 256-row two-stage DMA form (VAR 7) 10-20 % slower on these K depths
+// ("what bounds the contraction kernel").  ctx->variant selects the others.
 template <int AMODE, bool BIAS, bool ACC>
 int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, double bytes) {
   if (AMODE == 1 && !BIAS && !ACC) {
@@ -653,8 +778,17 @@ int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, doubl
       return launch_cfg<1, 4, 1, 2, 3, false, false, 3>(ctx, a, "igemm_conv_256x96", kbytes, ops, bytes);
     if (ctx->variant == 4 && a.N % 256 == 0)  // 256 x 256 tile, 8 waves, two stages
       return launch_cfg<1, 2, 4, 4, 2, false, false, 0>(ctx, a, "igemm_conv_256x256", kbytes, ops, bytes);
+    if (ctx->variant == 7 && a.N > 128 && (long)((a.M + 255) / 256) >= 256) {
+      // 4 waves of 128 x 128 or 128 x 96: whichever pads N less
+      const int pad4 = (a.N + 255) / 256 * 256, pad3 = (a.N + 191) / 192 * 192;
+      if (pad4 <= pad3) return launch_cfg<1, 2, 2, 4, 4, false, false, 7>(ctx, a, "igemm_conv_256x256", kbytes, ops, bytes);
+      return launch_cfg<1, 2, 2, 4, 3, false, false, 7>(ctx, a, "igemm_conv_256x192", kbytes, ops, bytes);
+    }
   }
-  return launch_tile_var<AMODE, BIAS, ACC, 3>(ctx, a, kbytes, ops, bytes);
+  // Linear (few, short split-K slices per block) measured 20 % slower with DMA staging: register staging there
+  if (ctx->variant == 3 || (AMODE == 0 && ctx->variant != 5))
+    return launch_tile_var<AMODE, BIAS, ACC, 3>(ctx, a, kbytes, ops, bytes);
+  return launch_tile_var<AMODE, BIAS, ACC, 5>(ctx, a, kbytes, ops, bytes);
 }
 
 }  // namespace

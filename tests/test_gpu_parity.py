@@ -326,3 +326,38 @@ def test_conv_batch_invariance_fused_at_bench_size(gpu, orc):
                                         cs["s_out"], cs["zp_out"], stride=1, pad=1, in_nhwc=True, out_nhwc=True,
                                         want_acc=False, in_border=1, out_border=1)
     assert np.array_equal(out[:4], cs["out"]) and np.array_equal(out[-4:], cs["out"])
+
+
+# ---- large-tile contraction kernels (256 x 256 / 256 x 192 block tiles, LDS-DMA staging) --------------
+# Selected for M >= 65 281 rows and N > 128 features; every output byte and INT32 accumulator of the whole
+# batch against the oracle, for the compiled staging variants (0 = default, 5 = one-stage DMA, 7 = two-stage
+# DMA with 256-row tiles): ragged N (masked feature tiles, scalar store path), K tails that end inside a
+# 128-byte K tile, stride 2, bordered outputs, fused relu.
+LARGE_GEOMS = [
+    (400, 128, 13, 13, 256, 3, 1, 1),  # N = 256: one 256-wide feature tile
+    (400, 64, 13, 13, 384, 3, 1, 1),   # N = 384: two 192-wide tiles; K = 576 = 4.5 K tiles
+    (400, 32, 13, 13, 320, 3, 1, 1),   # N = 320: second 192-wide tile two-thirds full; K = 288
+    (100, 96, 27, 27, 200, 5, 1, 2),   # N = 200 (not a multiple of 16: scalar stores), K = 2400, 5 x 5
+    (300, 16, 31, 31, 256, 3, 2, 1),   # stride 2, K = 144 (a little over one K tile)
+]
+
+
+@pytest.mark.parametrize("variant", [0, 5, 7])
+@pytest.mark.parametrize("geom", LARGE_GEOMS)
+def test_conv_large_tiles_bit_exact(gpu, orc, geom, variant):
+    n, c, h, w, kc, k, stride, pad = geom
+    cs = synth.conv_case(orc, 77 + sum(geom), n, c, h, w, kc, k, stride, pad)
+    lib = abi.lib()
+    abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, variant))
+    try:
+        for relu, ob, want_acc in ((False, 0, True), (True, 1 if kc % 16 == 0 else 0, False)):
+            out, acc, _ = gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"],
+                                                  cs["s_w"], cs["s_out"], cs["zp_out"], stride=stride, pad=pad,
+                                                  in_nhwc=True, out_nhwc=True, relu=relu, in_border=pad,
+                                                  out_border=ob, want_acc=want_acc)
+            want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
+            if want_acc:
+                assert np.array_equal(acc, cs["acc"])
+            assert np.array_equal(out, want)
+    finally:
+        abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))

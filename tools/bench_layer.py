@@ -18,6 +18,15 @@ LAYERS = {  # name: (n, c, h, w, kc, k, stride, pad)
     "conv3": (1000, 256, 13, 13, 384, 3, 1, 1),
     "conv4": (1000, 384, 13, 13, 384, 3, 1, 1),
     "conv5": (1000, 384, 13, 13, 256, 3, 1, 1),
+    # K sweep at a fixed tile count (per-tile overhead vs k-loop rate): 13 x 13, N = 384
+    "c128": (1000, 128, 13, 13, 384, 3, 1, 1),
+    "c256": (1000, 256, 13, 13, 384, 3, 1, 1),
+    "c512": (1000, 512, 13, 13, 384, 3, 1, 1),
+    "c768": (1000, 768, 13, 13, 384, 3, 1, 1),
+    "c1024": (1000, 1024, 13, 13, 384, 3, 1, 1),
+    # the same with 768 * k tiles exactly (M = 128 * 256 * 3 / 3 rows, N = 384): no partial last round
+    "full256": (768, 256, 16, 16, 384, 3, 1, 1),
+    "full768": (768, 768, 16, 16, 384, 3, 1, 1),
 }
 
 

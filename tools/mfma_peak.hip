@@ -10,6 +10,7 @@
 //   mode 7: staging by LDS-DMA: 8 x global_load_lds_dwordx4 per thread per tile (L2-resident source),
 //           issued before the MFMAs, vmcnt(0) + barrier after them; no ds_write at all
 //   mode 8: as 7 with the DMA issue spread over the k-steps (2 per k-step)
+//   mode 10: as 9 with the A tile staged by LDS-DMA (global_load_lds b128) instead of VGPRs + ds_write
 //   mode 9: B fragments straight from a fragment-ordered global panel (1 KiB coalesced per wave-load,
 //           L2/L1 resident, loaded one tile ahead), A through LDS: 2 A-fragment reads per k-step,
 //           4 ds_write_b128 per thread per tile, one barrier
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void k(int iters, int* out, const unsigned cha
   v4i st[8];
   for (int i = 0; i < 8; ++i) st[i] = v4i{tid + i, i, 3, 4};
   v4i bq[2][2][4];  // mode 9: [parity][n-tile][k-step]
-  if (MODE == 9) {
+  if (MODE == 9 || MODE == 10) {
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void k(int iters, int* out, const unsigned cha
   // DMA: lane's global source (1 KiB per wave-instruction, 16 B per lane), L2-resident 64 KiB window per block
   const unsigned char* gp = gsrc + (size_t)(blockIdx.x & 255) * 65536 + tid * 16;
   for (int it = 0; it < iters; ++it) {
-    if (MODE == 9) {
+    if (MODE == 9 || MODE == 10) {
       // static register parity: two tiles per loop trip
 #pragma unroll
       for (int par = 0; par < 2; ++par) {
@@ -67,7 +68,10 @@ __global__ __launch_bounds__(256) void k(int iters, int* out, const unsigned cha
 #pragma unroll
             for (int n = 0; n < 2; ++n)
               acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bq[par][n][ks], a[m], acc[m][n], 0, 0, 0);
-          *reinterpret_cast<v4i*>(smem + 256 * 144 + wr + ks * 32 * 144) = st[ks] ^ (int)0x80808080;
+          if (MODE == 9) *reinterpret_cast<v4i*>(smem + 256 * 144 + wr + ks * 32 * 144) = st[ks] ^ (int)0x80808080;
+          if (MODE == 10)  // A tile of the next k-block by LDS-DMA: 4 x 1 KiB per wave per tile, one per k-step
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + ((it * 4 + par * 4 + ks) & 15) * 4096),
+                                             (__attribute__((address_space(3))) void*)(smem + 256 * 144 + wave * 1024 + ks * 4096), 16, 0, 0);
         }
         __syncthreads();
       }
@@ -136,6 +140,201 @@ __global__ __launch_bounds__(256) void k(int iters, int* out, const unsigned cha
   out[blockIdx.x * 256 + tid] = s;
 }
 
+
+// ---- 256 x 256 block tile, 4 waves of 128 x 128 (16 accumulator tiles = 256 AGPRs per lane) -------------
+//   mode 0: LDS structure only: per k-step 4+4 fragment reads, 16 MFMAs, 4 ds_write_b128 from registers
+//           into the other stage; one barrier per 128-deep k-block
+//   mode 1: as 0 with the staged data loaded from an L2-resident global window (16 x 16 B per thread per k-block)
+//   mode 2: as 1 with the ds_writes replaced by LDS-DMA
+template <int MODE>
+__global__ __launch_bounds__(256) void k2(int iters, int* out, const unsigned char* gsrc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages x 512 rows x 144 B
+  constexpr int STAGE = 512 * 144;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  v16i acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = r + tid;
+  for (int i = tid; i < 2 * STAGE / 4; i += 256) reinterpret_cast<int*>(smem)[i] = i * 2654435761u;
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ard = (wm * 128 + (lane & 31)) * 144 + (lane >> 5) * 16;
+  const int brd = 256 * 144 + (wn * 128 + (lane & 31)) * 144 + (lane >> 5) * 16;
+  const int wr = (tid >> 3) * 144 + (tid & 7) * 16;  // 32 rows x 128 B per pass of the block
+  v4i st[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st[i] = v4i{tid + i, i, 3, 4};
+  const unsigned char* gp = gsrc + (size_t)(blockIdx.x & 255) * 65536 + tid * 16;
+  for (int it = 0; it < iters; ++it) {
+    const unsigned char* cur = smem + (it & 1) * STAGE;
+    unsigned char* nxt = smem + ((it & 1) ^ 1) * STAGE;
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[i] = *reinterpret_cast<const v4i*>(gp + ((it * 16 + i) & 15) * 4096);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v4i a[4], b[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const v4i*>(cur + ard + m * 32 * 144 + ks * 32);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const v4i*>(cur + brd + n * 32 * 144 + ks * 32);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[n], a[m], acc[m][n], 0, 0, 0);
+      if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + ((it * 16 + ks * 4 + i) & 15) * 4096),
+                                           (__attribute__((address_space(3))) void*)(nxt + wave * 1024 + (ks * 4 + i) * 4096), 16, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<v4i*>(nxt + wr + (ks * 4 + i) * 32 * 144) = st[ks * 4 + i] ^ (int)0x80808080;
+      }
+    }
+    __syncthreads();
+    if (MODE == 0) st[it & 15].x += acc[0][0][0];
+  }
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int MODE>
+void run2(const char* name) {
+  int* out;
+  unsigned char* gsrc;
+  const int blocks = 256, iters = 2000;
+  hipMalloc(&out, blocks * 256 * 4);
+  hipMalloc(&gsrc, 256 * 65536 + 65536);
+  hipMemset(gsrc, 1, 256 * 65536 + 65536);
+  const int lds = 2 * 512 * 144;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k2<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  k2<MODE><<<blocks, 256, lds>>>(200, out, gsrc);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k2<MODE><<<blocks, 256, lds>>>(iters, out, gsrc);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  hipError_t err = hipGetLastError();
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double ops = (double)blocks * 4 * iters * 64 * 65536.0;
+  printf("%-36s 256x256/4 waves, 1 block/CU: %.3f ms  %.0f TOPS  (%s)\n", name, ms, ops / (ms * 1e-3) / 1e12, hipGetErrorString(err));
+  hipFree(out);
+  hipFree(gsrc);
+}
+
+// ---- structure sweep: 4 waves (2 x 2), wave tile TM x TN MFMA tiles, LDS-DMA staging, NST stages ----------
+template <int TM, int TN, int NST>
+__global__ __launch_bounds__(256) void k3(int iters, int* out, const unsigned char* gsrc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROWS = 64 * (TM + TN);   // A rows + B rows of the block tile
+  constexpr int STAGE = ROWS * 128;      // unpadded (the DMA writes 1 KiB runs); reads below use a swizzle
+  constexpr int NDMA = ROWS / 8 / 4;     // 1 KiB wave-instructions per wave per k-block
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  v16i acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = r + tid;
+  for (int i = tid; i < NST * STAGE / 4; i += 256) reinterpret_cast<int*>(smem)[i] = i * 2654435761u;
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1;
+  int ard[4], brd[4];  // per k-step swizzled fragment addresses: chunk (2 ks + hi) ^ (row & 7)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int sw = ((ks * 2 + (lane >> 5)) ^ (lane & 7)) * 16;
+    ard[ks] = (wm * TM * 32 + (lane & 31)) * 128 + sw;
+    brd[ks] = (2 * TM * 32 + wn * TN * 32 + (lane & 31)) * 128 + sw;
+  }
+  const unsigned char* gp = gsrc + (size_t)(blockIdx.x & 255) * 65536 + tid * 16;
+  for (int it = 0; it < iters; ++it) {
+    const unsigned char* cur = smem + (NST == 2 ? (it & 1) * STAGE : 0);
+    unsigned char* nxt = smem + (NST == 2 ? ((it & 1) ^ 1) * STAGE : 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v4i a[TM], b[TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) a[m] = *reinterpret_cast<const v4i*>(cur + ard[ks] + m * 4096);
+#pragma unroll
+      for (int n = 0; n < TN; ++n) b[n] = *reinterpret_cast<const v4i*>(cur + brd[ks] + n * 4096);
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[n], a[m], acc[m][n], 0, 0, 0);
+      if (NST == 2) {
+#pragma unroll
+        for (int i = ks * NDMA / 4; i < (ks + 1) * NDMA / 4; ++i)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + ((it * NDMA + i) & 15) * 4096),
+                                           (__attribute__((address_space(3))) void*)(nxt + wave * 1024 + i * 4096), 16, 0, 0);
+      }
+    }
+    if (NST == 1) {
+      __syncthreads();  // every wave is done reading the stage
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + ((it * NDMA + i) & 15) * 4096),
+                                         (__attribute__((address_space(3))) void*)(nxt + wave * 1024 + i * 4096), 16, 0, 0);
+    }
+    __syncthreads();
+  }
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int TM, int TN, int NST>
+void run3(int blocks_per_cu) {
+  int* out;
+  unsigned char* gsrc;
+  const int blocks = 256 * blocks_per_cu, iters = 2000;
+  hipMalloc(&out, blocks * 256 * 4);
+  hipMalloc(&gsrc, 256 * 65536 + 65536);
+  hipMemset(gsrc, 1, 256 * 65536 + 65536);
+  const int lds = NST * 64 * (TM + TN) * 128;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k3<TM, TN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  int occ = 0;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k3<TM, TN, NST>, 256, lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  k3<TM, TN, NST><<<blocks, 256, lds>>>(200, out, gsrc);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k3<TM, TN, NST><<<blocks, 256, lds>>>(iters, out, gsrc);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  hipError_t err = hipGetLastError();
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double ops = (double)blocks * 4 * iters * 4 * TM * TN * 65536.0;
+  printf("DMA sweep: wave tile %dx%d (block %dx%d) stages %d launched %d/CU (occupancy %d): %.3f ms  %.0f TOPS  (%s)\n", TM, TN,
+         TM * 64, TN * 64, NST, blocks_per_cu, occ, ms, ops / (ms * 1e-3) / 1e12, hipGetErrorString(err));
+  hipFree(out);
+  hipFree(gsrc);
+}
+
 template <int MODE>
 void run(const char* name, int blocks_per_cu) {
   int* out;
@@ -173,6 +372,22 @@ int main() {
     run<7>("LDS-DMA staging, up front", b);
     run<8>("LDS-DMA staging, spread", b);
     run<9>("B direct from global, A via LDS", b);
+    run<10>("B direct, A by LDS-DMA", b);
   }
+  run2<0>("LDS structure only");
+  run2<1>("global loads + ds_write");
+  run2<2>("LDS-DMA");
+  run3<4, 4, 2>(1);
+  run3<4, 4, 1>(1);
+  run3<4, 3, 2>(1);
+  run3<4, 2, 2>(1);
+  run3<4, 2, 1>(2);
+  run3<4, 2, 1>(3);
+  run3<2, 4, 2>(1);
+  run3<2, 4, 1>(2);
+  run3<2, 2, 2>(2);
+  run3<2, 2, 2>(3);
+  run3<2, 2, 1>(3);
+  run3<2, 2, 1>(4);
   return 0;
 }
