@@ -778,6 +778,14 @@ int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, doubl
       return launch_cfg<1, 4, 1, 2, 3, false, false, 3>(ctx, a, "igemm_conv_256x96", kbytes, ops, bytes);
     if (ctx->variant == 4 && a.N % 256 == 0)  // 256 x 256 tile, 8 waves, two stages
       return launch_cfg<1, 2, 4, 4, 2, false, false, 0>(ctx, a, "igemm_conv_256x256", kbytes, ops, bytes);
+    if (ctx->variant == 8 && a.N > 64)  // 256 x 128, 4 waves of 128 x 64, one DMA stage
+      return launch_cfg<1, 2, 2, 4, 2, false, false, 5>(ctx, a, "igemm_conv_256x128", kbytes, ops, bytes);
+    if (ctx->variant == 9 && a.N > 128)  // 128 x 256, 4 waves of 64 x 128
+      return launch_cfg<1, 2, 2, 2, 4, false, false, 5>(ctx, a, "igemm_conv_128x256", kbytes, ops, bytes);
+    // 192 x 128, 4 waves of 96 x 64, one DMA stage: 6.4 KB staged per MOP (128 x 128: 7.6) at three blocks
+    // per CU; measured 2.5-4 % faster than 128 x 128 on AlexNet conv2-5 (variant 12 = 128 x 128 everywhere)
+    if ((ctx->variant == 0 || ctx->variant == 11) && a.N > 64 && a.M >= 192 * 256)
+      return launch_cfg<1, 2, 2, 3, 2, false, false, 5>(ctx, a, "igemm_conv_192x128", kbytes, ops, bytes);
     if (ctx->variant == 7 && a.N > 128 && (long)((a.M + 255) / 256) >= 256) {
       // 4 waves of 128 x 128 or 128 x 96: whichever pads N less
       const int pad4 = (a.N + 255) / 256 * 256, pad3 = (a.N + 191) / 192 * 192;
