@@ -10,8 +10,9 @@
 //     path that is exact by the same argument as the requantiser's, IEEE sequence as fallback;
 //   * conv_smallc_kernel: persistent blocks, one wave per 32 output features whose weight slice
 //     [32][K] lives in VGPRs for the whole kernel (no B traffic, no LDS for B); a block walks bands
-//     of RB output rows, each band's input patch is a CONTIGUOUS piece of the grouped image, copied
-//     once into LDS (re-biased ^0x80) while the previous band is being multiplied; an MFMA A
+//     of RB output rows, each band's input patch is a CONTIGUOUS piece of the grouped image (stored
+//     already re-biased ^0x80 by the repack kernels), copied once into LDS by LDS-DMA (1 KiB per
+//     wave-instruction, no VGPR pass) while the previous band is being multiplied; an MFMA A
 //     fragment is one ds_read_b128 at base(pixel) + offset(tap); epilogue = the igemm requantiser,
 //     wave-private LDS transpose, 16-byte NHWC stores.
 // INT32 accumulators are the reference's sums (K order permuted, padded taps have zero weights).
@@ -46,7 +47,7 @@ __device__ __forceinline__ uint32_t frequant_pack4(int c0, int c1, int c2, int c
     packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(e, lof), r, packed);
     worst = __builtin_fminf(worst, __builtin_fabsf(__builtin_amdgcn_fractf(e) - 0.5f));
   }
-  if (worst >= 2.44140625e-4f) return packed;
+  if (worst >= 1.220703125e-4f) return packed;  // 2^-13 > 9.2e-5, the proven error bound
   packed = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) packed |= (uint32_t)frequant_exact((float)c[r], q, lo) << (8 * r);
@@ -56,7 +57,8 @@ __device__ __forceinline__ uint32_t frequant_pack4(int c0, int c1, int c2, int c
 constexpr int kMaxKS = 24;
 
 struct FirstArgs {
-  const uint8_t* img;  // grouped u8 image [n][Hp][WG][16]
+  const uint8_t* img;  // grouped image [n][Hp][WG][16], bytes re-biased (^0x80)
+  size_t img_bytes;
   int Hp;
   int KH, KWG, sh, swg, OH, OW;
   int RB, bands_per_img, total_bands;
@@ -126,7 +128,9 @@ __global__ __launch_bounds__(256) void quantize_repack_kernel(const float* __res
       }
       wds[px] = d;
     }
-    reinterpret_cast<uint4*>(out)[e] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+    // stored re-biased (u8 ^ 0x80 = s8 + 128 - 128): the contraction kernel's signed MFMA operand as is
+    reinterpret_cast<uint4*>(out)[e] =
+        make_uint4(wds[0] ^ 0x80808080u, wds[1] ^ 0x80808080u, wds[2] ^ 0x80808080u, wds[3] ^ 0x80808080u);
   }
 }
 
@@ -136,7 +140,9 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
   const int nthreads = blockDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = lane >> 5;
-  const int patch_bytes = p.PR * p.WG * 16;
+  const int nwaves = nthreads >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int patch_bytes = (p.PR * p.WG * 16 + 1023) & ~1023;  // LDS pitch of a patch: whole 1 KiB DMA pieces
   uint8_t* scratch = smem + 2 * patch_bytes + wave * (32 * 36);  // wave-private 32 px x 36 B
 
   // ---- this wave's weight slice -> registers (stays for the whole kernel) ---------------------
@@ -157,7 +163,8 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
   for (int j = 0; j < KS; ++j) koff[j] = hh ? p.toff[2 * j + 1] : p.toff[2 * j];
 
   const int groups = p.PR * p.WG;
-  const int fill_iters = (groups + nthreads - 1) / nthreads;
+  const int pieces = (groups + 63) >> 6;                    // 1 KiB DMA wave-instructions per patch
+  const int fill_iters = (pieces + nwaves - 1) / nwaves;    // iterations in which every wave issues one
   const FRequant rq = p.rq;
   const int lo = p.relu_lo;
   const float lof = (float)lo;
@@ -168,22 +175,30 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
     rb0 = (band - img * p.bands_per_img) * p.RB;
     rows = p.OH - rb0 < p.RB ? p.OH - rb0 : p.RB;
   };
-  // a band's patch = PR consecutive rows of the grouped image = one contiguous run of 16-byte groups
-  auto band_src = [&](int band) -> const v4i* {
+  // a band's patch = PR consecutive rows of the grouped image = one contiguous run of 16-byte groups;
+  // the buffer descriptor covers exactly that run, so the last (partial) DMA piece reads zeros past it
+  auto band_rsrc = [&](int band) -> __amdgpu_buffer_rsrc_t {
     int img, rb0, rows;
     band_origin(band, img, rb0, rows);
-    return reinterpret_cast<const v4i*>(p.img) + ((size_t)img * p.Hp + (size_t)rb0 * p.sh) * p.WG;
+    const size_t off = ((size_t)img * p.Hp + (size_t)rb0 * p.sh) * p.WG * 16;
+    const size_t left = p.img_bytes - off;  // the last band of the last image is shorter than a full patch
+    const int bytes = left < (size_t)groups * 16 ? (int)left : groups * 16;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.img + off), 0, bytes, 0x00020000);
   };
-  auto fill_sync = [&](int band, uint8_t* dst) {
-    const v4i* src = band_src(band);
-    for (int e = tid; e < groups; e += nthreads)
-      *reinterpret_cast<v4i*>(dst + e * 16) = src[e] ^ (int)0x80808080;  // u8 -> s8 re-bias
+  // DMA piece q of a patch: 64 groups -> LDS bytes [q * 1024, +1024) of `dst`
+  auto dma_piece = [&](const __amdgpu_buffer_rsrc_t& rs, uint8_t* dst, int q) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16,
+                                             (q * 64 + lane) * 16, 0, 0, 0);
   };
 
   int band = blockIdx.x;
   if (band >= p.total_bands) return;
   int cur = 0;
-  fill_sync(band, smem);
+  {
+    const __amdgpu_buffer_rsrc_t rs0 = band_rsrc(band);
+    for (int q = wave_u; q < pieces; q += nwaves) dma_piece(rs0, smem, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
 
   for (; band < p.total_bands; band += gridDim.x) {
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
     const int ntiles = (npix + 31) >> 5;
     const int nband = band + gridDim.x;
     const bool has_next = nband < p.total_bands;
-    const v4i* nsrc = band_src(has_next ? nband : band);
+    const __amdgpu_buffer_rsrc_t nrs = band_rsrc(has_next ? nband : band);
     const uint8_t* patch = smem + cur * patch_bytes;
     uint8_t* npatch = smem + (cur ^ 1) * patch_bytes;
     const int iters = ntiles > fill_iters ? ntiles : fill_iters;
@@ -204,12 +219,12 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
     while (sc >= p.OW) { sc -= p.OW; ++sr; }
 
     for (int it = 0; it < iters; ++it) {
-      // (1) start fetching one group of the NEXT band's patch
-      const int e = tid + it * nthreads;
-      const bool do_fill = has_next && it < fill_iters && e < groups;
-      // unconditional load (index clamped): a branch here would put an s_waitcnt vmcnt(0) right behind it
-      const v4i fetched = nsrc[e < groups ? e : groups - 1];
-      // (2) one 32-pixel x 32-feature tile of the CURRENT band
+      // the next band's patch streams in beside the tiles of this band: one DMA piece per wave per iteration
+      {
+        const int q = it * nwaves + wave_u;
+        if (has_next && q < pieces) dma_piece(nrs, npatch, q);
+      }
+      // one 32-pixel x 32-feature tile of the CURRENT band
       if (it < ntiles) {
         // (row, col) of this lane's pixel: walked incrementally, no division
         const int r = pr < rows ? pr : rows - 1, col = pr < rows ? pc : p.OW - 1;
@@ -251,14 +266,13 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
           *reinterpret_cast<uint4*>(p.out + pix * p.N + wave * 32 + sh16 * 16) = val;
         }
       }
-      // (3) park the fetched group in the other patch buffer
-      if (do_fill) *reinterpret_cast<v4i*>(npatch + e * 16) = fetched ^ (int)0x80808080;
       // advance both pixel walks by 32 pixels
       pc += 32;
       while (pc >= p.OW) { pc -= p.OW; ++pr; }
       sc += 32;
       while (sc >= p.OW) { sc -= p.OW; ++sr; }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed
     __syncthreads();  // everyone done with patch[cur]; patch[cur^1] complete
     cur ^= 1;
   }
@@ -326,6 +340,7 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
     grouped = c.scratch;
   }
   a.img = grouped;
+  a.img_bytes = (size_t)c.n * a.Hp * a.WG * 16;
   // rows per band: as many as keep two patches within ~44 KB (3 blocks per CU)
   int RB = 1;
   while (RB < c.OH && (size_t)(RB * a.sh + c.KH) * a.WG * 16 * 2 <= 44 * 1024 && (RB + 1) * c.OW <= 512) ++RB;
@@ -348,7 +363,7 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
     a.toff[q] = q < nchunks ? (kh * a.WG + g) * 16 : 0;  // chunks past K carry zero weights
   }
   const int waves = c.N / 32, threads = waves * 64;
-  const size_t lds = (size_t)2 * a.PR * a.WG * 16 + (size_t)waves * 32 * 36;
+  const size_t lds = (size_t)2 * (((size_t)a.PR * a.WG * 16 + 1023) & ~(size_t)1023) + (size_t)waves * 32 * 36;
   int blocks = 256 * 2;  // resident blocks per CU (measured: 2 beats 3 and 4 on AlexNet conv1)
   if (blocks > a.total_bands) blocks = a.total_bands;
   const double ops = 2.0 * c.n * c.OH * c.OW * (double)c.N * c.c * c.KH * c.KW;

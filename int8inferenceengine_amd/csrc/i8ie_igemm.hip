@@ -51,7 +51,7 @@ __device__ __forceinline__ int requant_exact(float cf, const Requant& q, int lo)
 
 // e = fma(cf, ms, zp - 0.5), ms = fl(s_in*s_w/s_out): an estimate of (reference value v) - 0.5.
 // While -1 < v < 256, |v - (e + 0.5)| < 9.2e-5 (reference: 3 roundings on |C*s_in*s_w/s_out| < 256
-// and one on |v| < 257; e: one rounding of ms, one of the fma).  So if e is further than 2^-12
+// and one on |v| < 257; e: one rounding of ms, one of the fma).  So if e is further than 2^-13
 // from every half-integer, v lies strictly inside the unit interval [k, k+1) with k = rne(e), and
 // the reference's trunc + clamp equals sat_u8(rne(e)), which is exactly what v_cvt_pk_u8_f32
 // computes (round-to-nearest-even, saturate to [0, 255], insert into byte r).  Outside (-1, 256)
@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t requant_pack4(const int (&c)[4], const Requa
     packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(e, lof), r, packed);
     worst = __builtin_fminf(worst, __builtin_fabsf(__builtin_amdgcn_fractf(e) - 0.5f));
   }
-  if (worst >= 2.44140625e-4f) return packed;
+  if (worst >= 1.220703125e-4f) return packed;  // 2^-13 > 9.2e-5, the proven error bound
   packed = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) packed |= (uint32_t)requant_exact((float)c[r], q, lo) << (8 * r);
@@ -527,8 +527,14 @@ __global__ __launch_bounds__(256) void maxpool_u8_nhwc_kernel(const uint8_t* __r
                                                               uint8_t* __restrict__ out, int64_t total, int inHp,
                                                               int inWp, int ib, int c16, int oh, int ow, int k, int s,
                                                               int outHp, int outWp, int ob, uint32_t lo4) {
-  const int64_t gstride = (int64_t)gridDim.x * 256;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += gstride) {
+  // XCD-aware partition (gridDim.x % 8 == 0): blocks with equal blockIdx % 8 share an L2, so each of the
+  // eight groups sweeps one contiguous eighth of the output -- window rows shared by neighbouring output
+  // rows are then fetched into one L2 once (rocprofv3 FETCH_SIZE: 1.37x the input bytes without this)
+  const int64_t slab = ((total + 7) / 8 + 255) / 256 * 256;
+  const int64_t lo = (int64_t)(blockIdx.x & 7) * slab;
+  const int64_t hi = lo + slab < total ? lo + slab : total;
+  const int64_t gstride = (int64_t)(gridDim.x >> 3) * 256;
+  for (int64_t e = lo + (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x; e < hi; e += gstride) {
     const int cc = (int)(e % c16);
     int64_t t = e / c16;
     const int x = (int)(t % ow);
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(256) void fill_border_kernel(uint8_t* __restrict__ 
 // implicit GEMM with 16-byte-aligned, predicate-free gathers.
 __global__ __launch_bounds__(256) void repack_smallc_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                             int64_t total, int c, int h, int w, int Hp, int Wg,
-                                                            int ph, int pw, uint32_t zp) {
+                                                            int ph, int pw, uint32_t zp, uint32_t rebias) {
   const int64_t gstride = (int64_t)gridDim.x * 256;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += gstride) {
     const int g = (int)(e % Wg);
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(256) void repack_smallc_kernel(const uint8_t* __res
           v |= b << (8 * ch);
         }
       }
-      wds[px] = v;
+      wds[px] = v ^ rebias;  // 0x80808080 when the weights-stationary kernel (i8ie_first.hip) consumes it
     }
     reinterpret_cast<uint4*>(out)[e] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
   }
@@ -942,11 +948,12 @@ int i8ie_launch_fill_border(i8ie_ctx* ctx, uint8_t* out, int n, int c, int h, in
 }
 
 int i8ie_launch_repack_smallc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int Hp,
-                              int Wg, int ph, int pw, int zp) {
+                              int Wg, int ph, int pw, int zp, int rebias) {
   const int64_t total = (int64_t)n * Hp * Wg;
   I8ieProfScope prof(ctx, "repack_smallc_u8", 0.0, (double)n * c * h * w + 16.0 * total);
   repack_smallc_kernel<<<cap_grid(total, 256), 256, 0, ctx->stream>>>(in, out, total, c, h, w, Hp, Wg, ph, pw,
-                                                                      (uint32_t)(zp & 0xFF));
+                                                                      (uint32_t)(zp & 0xFF),
+                                                                      rebias ? 0x80808080u : 0u);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }
@@ -956,7 +963,7 @@ int i8ie_launch_maxpool_nhwc(i8ie_ctx* ctx, const uint8_t* in, int ib, uint8_t* 
   const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
   const int64_t total = (int64_t)n * oh * ow * (c / 16);
   I8ieProfScope prof(ctx, "maxpool_u8_nhwc", 0.0, (double)n * c * h * w + 16.0 * total);
-  maxpool_u8_nhwc_kernel<<<cap_grid(total, 256, 256 * 32), 256, 0, ctx->stream>>>(
+  maxpool_u8_nhwc_kernel<<<(cap_grid(total, 256, 256 * 32) + 7) / 8 * 8, 256, 0, ctx->stream>>>(
       in, out, total, h + 2 * ib, w + 2 * ib, ib, c / 16, oh, ow, k, s, oh + 2 * ob, ow + 2 * ob, ob,
       (uint32_t)(relu_zp & 0xFF) * 0x01010101u);
   I8IE_LAUNCH_CHECK();

@@ -31,7 +31,7 @@ int i8ie_launch_nhwc_to_nchw(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int
 int i8ie_launch_reborder(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int ib, int ob,
                          int zp);
 int i8ie_launch_repack_smallc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int Hp,
-                              int Wg, int ph, int pw, int zp);
+                              int Wg, int ph, int pw, int zp, int rebias);
 int i8ie_launch_fill_border(i8ie_ctx* ctx, uint8_t* out, int n, int c, int h, int w, int b, int zp);
 int i8ie_launch_maxpool_nhwc(i8ie_ctx* ctx, const uint8_t* in, int ib, uint8_t* out, int ob, int n, int c, int h,
                              int w, int k, int s, int relu_zp);
@@ -568,8 +568,9 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
       src = ws;
     }
     uint8_t* rep = ws + t_bytes;
-    I8IE_TRY(i8ie_launch_repack_smallc(ctx, src, rep, m, cg.c, cg.h, cg.w, Hp, Wg, cg.pad, cg.pad, zp_in));
-    if (acc == nullptr && i8ie_first_supported(cg.c, cg.stride, L->n, L->K2, cg.kh, L->kwg, cg.ow)) {
+    const bool wstat = acc == nullptr && i8ie_first_supported(cg.c, cg.stride, L->n, L->K2, cg.kh, L->kwg, cg.ow);
+    I8IE_TRY(i8ie_launch_repack_smallc(ctx, src, rep, m, cg.c, cg.h, cg.w, Hp, Wg, cg.pad, cg.pad, zp_in, wstat));
+    if (wstat) {
       // weights-stationary small-C kernel (i8ie_first.hip) on the grouped image
       uint8_t* dst = o_bytes ? ws + t_bytes + r_bytes : out;
       const int ob = o_bytes ? 0 : out_border;
