@@ -16,6 +16,8 @@
 //     fragment is one ds_read_b128 at base(pixel) + offset(tap); epilogue = the igemm requantiser,
 //     wave-private LDS transpose, 16-byte NHWC stores.
 // INT32 accumulators are the reference's sums (K order permuted, padded taps have zero weights).
+#include <cstdlib>
+
 #include "i8ie_internal.h"
 
 namespace {
@@ -343,7 +345,9 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
   a.img_bytes = (size_t)c.n * a.Hp * a.WG * 16;
   // rows per band: as many as keep two patches within ~44 KB (3 blocks per CU)
   int RB = 1;
-  while (RB < c.OH && (size_t)(RB * a.sh + c.KH) * a.WG * 16 * 2 <= 44 * 1024 && (RB + 1) * c.OW <= 512) ++RB;
+  size_t patch_budget = 44 * 1024;  // bytes for the two patches of a block
+  if (const char* e = std::getenv("I8IE_FIRST_PATCH_KB")) patch_budget = (size_t)std::atoi(e) * 1024;
+  while (RB < c.OH && (size_t)(RB * a.sh + c.KH) * a.WG * 16 * 2 <= patch_budget && (RB + 1) * c.OW <= 512) ++RB;
   a.RB = RB;
   a.PR = (RB - 1) * a.sh + c.KH;
   a.bands_per_img = (c.OH + RB - 1) / RB;
@@ -364,7 +368,9 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
   }
   const int waves = c.N / 32, threads = waves * 64;
   const size_t lds = (size_t)2 * (((size_t)a.PR * a.WG * 16 + 1023) & ~(size_t)1023) + (size_t)waves * 32 * 36;
-  int blocks = 256 * 2;  // resident blocks per CU (measured: 2 beats 3 and 4 on AlexNet conv1)
+  int per_cu = 3;  // blocks launched per CU (measured on AlexNet conv1 with the DMA fill: 3 beats 2, 4 and 6)
+  if (const char* e = std::getenv("I8IE_FIRST_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : per_cu;
+  int blocks = 256 * per_cu;
   if (blocks > a.total_bands) blocks = a.total_bands;
   const double ops = 2.0 * c.n * c.OH * c.OW * (double)c.N * c.c * c.KH * c.KW;
   const double bytes = 16.0 * c.n * a.Hp * a.WG + (double)c.n * c.OH * c.OW * c.N;
