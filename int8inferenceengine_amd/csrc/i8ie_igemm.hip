@@ -24,6 +24,7 @@
 //     an exact-sequence fallback near rounding boundaries; optional fused ReLU
 //     (src/functional.cc:15-26); optional physically padded output.
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "i8ie_internal.h"
@@ -829,11 +830,49 @@ struct I8ieIgemmCall {
   int32_t* partial;
 };
 
+// The gathers address A with 32-bit buffer offsets.  A batch whose activations exceed that range (288 GB of
+// HBM hold far more than 4 GiB) runs as several launches over whole images / rows; $I8IE_IGEMM_CHUNK_BYTES
+// lowers the limit so that tests can walk the chunk loop with small tensors.
+static size_t igemm_chunk_limit() {
+  static const size_t v = [] {
+    const char* e = std::getenv("I8IE_IGEMM_CHUNK_BYTES");
+    const size_t hard = ((size_t)1 << 32) - 4096;
+    const size_t want = e ? (size_t)std::strtoull(e, nullptr, 10) : hard;
+    return want > 0 && want < hard ? want : hard;
+  }();
+  return v;
+}
+
 int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   I8IE_REQUIRE(c.M > 0 && c.N > 0 && c.Kpad > 0 && c.Kpad % BK2 == 0, "igemm dimensions");
   I8IE_REQUIRE((reinterpret_cast<uintptr_t>(c.A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(c.B) & 15u) == 0,
                "operands must be 16-byte aligned");
-  I8IE_REQUIRE(c.a_bytes < ((size_t)1 << 32) - 4096, "activation tensor must be < 4 GiB");
+  if (c.a_bytes >= igemm_chunk_limit()) {
+    const size_t limit = igemm_chunk_limit();
+    const int P = c.amode == 1 ? c.OH * c.OW : 1;  // rows per unit (image / row)
+    const size_t unit_in = c.amode == 1 ? (size_t)c.Hp * c.Wp * c.C : (size_t)c.lda;
+    const int ob = c.amode == 1 ? c.ob : 0;
+    const size_t unit_out = c.amode == 1 ? (size_t)(c.OH + 2 * ob) * (c.OW + 2 * ob) * c.N : (size_t)c.N;
+    I8IE_REQUIRE(c.M % P == 0 && unit_in > 0 && unit_in < limit, "igemm: one image / row exceeds the offset range");
+    const int units = c.M / P;
+    int per = (int)((limit - 1) / unit_in);
+    if (per < 1) per = 1;
+    if (c.amode == 1 && (size_t)per * unit_out % 16 != 0) per -= per % 16;  // keep 16-byte aligned sub-outputs
+    if (per < 1) per = 1;
+    for (int u0 = 0; u0 < units; u0 += per) {
+      const int nb = units - u0 < per ? units - u0 : per;
+      I8ieIgemmCall sub = c;
+      sub.A = c.A + (size_t)u0 * unit_in;
+      const size_t left = c.a_bytes - (size_t)u0 * unit_in;
+      sub.a_bytes = left < (size_t)nb * unit_in ? left : (size_t)nb * unit_in;
+      sub.M = nb * P;
+      sub.out = c.out + (size_t)u0 * unit_out;
+      if (c.acc) sub.acc = c.acc + (size_t)u0 * P * c.N;
+      I8IE_REQUIRE(sub.a_bytes < limit, "igemm: chunking failed to fit the offset range");
+      I8IE_TRY(i8ie_igemm_launch(ctx, sub));
+    }
+    return I8IE_OK;
+  }
   IgemmArgs a{};
   a.A = c.A;
   a.a_bytes = (unsigned)c.a_bytes;

@@ -361,3 +361,35 @@ def test_conv_large_tiles_bit_exact(gpu, orc, geom, variant):
             assert np.array_equal(out, want)
     finally:
         abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
+
+
+def test_conv_and_linear_chunked_over_the_32bit_offset_range(orc):
+    """Activations beyond the 32-bit offset range run as several launches over whole images / rows.  The limit
+    is lowered through $I8IE_IGEMM_CHUNK_BYTES in a child process (it is read once per process) so that the
+    chunk loop is walked with small tensors: 7 images per launch for the conv, 26 rows for the Linear."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
+import int8inferenceengine_amd, abi, synth, orc
+g = abi.Ctx(0)
+cs = synth.conv_case(orc, 5, 23, 32, 9, 9, 48, 3, 1, 1)           # 11*11*32 = 3872 B per bordered image
+for relu, ob in ((False, 0), (True, 2)):
+    out, acc, _ = g.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
+                                        cs["s_out"], cs["zp_out"], stride=1, pad=1, in_nhwc=True, out_nhwc=True,
+                                        relu=relu, in_border=1, out_border=ob)
+    want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
+    assert np.array_equal(acc, cs["acc"]) and np.array_equal(out, want)
+ls = synth.linear_case(orc, 6, 70, 1024, 200)                      # 1024 B per row: 26 rows per launch
+out, acc = g.layer_forward("linear", ls["q_in"], ls["qw"], ls["qb"], ls["s_in"], ls["zp_in"], ls["s_w"], ls["s_out"],
+                           ls["zp_out"])
+assert np.array_equal(acc, ls["acc"]) and np.array_equal(out, ls["out"])
+print("chunked ok")
+'''
+    env = dict(os.environ, I8IE_IGEMM_CHUNK_BYTES=str(7 * 3872 + 100))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "chunked ok" in r.stdout, r.stdout + r.stderr
