@@ -215,7 +215,11 @@ int i8ie_layer_forward(i8ie_layer* layer, const uint8_t* in_dev, int m, int h, i
  * src/conv2d.cc:24-28 is materialised by the producer).  When out_border > 0 the call writes
  * only the interior of `out`: the border bytes are the caller's (i8ie_fill_border_u8 with
  * zp_out, once per buffer: they stay valid while the buffer is reused for the same tensor).
- * i8ie_layer_preferred_layout tells which output layout avoids a conversion. */
+ * i8ie_layer_preferred_layout tells which output layout avoids a conversion.
+ * Linear layers: layouts do not apply to [m][k] rows, with one exception -- in_layout = NHWC together with
+ * h, w > 1 declares the rows to be a flattened NHWC activation [m][h][w][c] (c = in_features / (h*w)) rather
+ * than the reference's flattened NCHW (`x.reshape(n, -1)` of a Tensor<u8_t>, include/tensor.h:106-133): the
+ * layer then walks K in (h, w, c) order with a weight panel permuted once, sparing the transpose. */
 int i8ie_layer_forward_fused(i8ie_layer* layer, const uint8_t* in_dev, int in_layout, int in_border, int m,
                              int h, int w, float s_in, uint8_t zp_in, int relu, uint8_t* out_dev,
                              int out_layout, int out_border, int32_t* acc_dbg_dev);

@@ -177,17 +177,31 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
   // (slot = lane), so the swizzle picks the source chunk instead: c = slot ^ (row & 7)
   const int cA = DMA ? ((tid & 7) ^ ((tid >> 3) & 7)) : (tid & 7);
   unsigned a_off[A_PER], b_off[B_PER];
+  // AMODE 1: physical pixel index of this thread's row i in a bordered output (the store loop of the epilogue
+  // walks the same rows).  One division for the first row, then a walk of NT/8 pixels per row.
+  unsigned o_pix[(AMODE == 1) ? A_PER : 1];
+  if (AMODE == 0) {
 #pragma unroll
-  for (int i = 0; i < A_PER; ++i) {
-    int gr = m0 + (tid >> 3) + (NT >> 3) * i;
-    gr = gr < p.M ? gr : p.M - 1;  // rows past M: computed, never stored
-    if (AMODE == 0) {
+    for (int i = 0; i < A_PER; ++i) {
+      int gr = m0 + (tid >> 3) + (NT >> 3) * i;
+      gr = gr < p.M ? gr : p.M - 1;  // rows past M: computed, never stored
       a_off[i] = (unsigned)gr * p.lda;
-    } else {
-      const int P = p.OH * p.OW;
-      const int img = gr / P, rem = gr - img * P;
-      const int oh = rem / p.OW, ow = rem - oh * p.OW;
-      a_off[i] = (unsigned)img * p.img_pitch + (unsigned)(oh * p.sh) * p.row_pitch + (unsigned)(ow * p.sw) * p.C;
+    }
+  } else {
+    const int P = p.OH * p.OW;
+    const int gr0 = m0 + (tid >> 3);
+    int img = gr0 / P;
+    const int rem = gr0 - img * P;
+    int oh = rem / p.OW, ow = rem - oh * p.OW;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const bool past = gr0 + (NT >> 3) * i >= p.M;  // rows past M read the last pixel: computed, never stored
+      const int im = past ? p.M / P - 1 : img, y = past ? p.OH - 1 : oh, x = past ? p.OW - 1 : ow;
+      a_off[i] = (unsigned)im * p.img_pitch + (unsigned)(y * p.sh) * p.row_pitch + (unsigned)(x * p.sw) * p.C;
+      o_pix[i] = ((unsigned)im * p.OHp + y + p.ob) * p.OWp + x + p.ob;
+      ow += NT >> 3;
+      while (ow >= p.OW) { ow -= p.OW; ++oh; }
+      while (oh >= p.OH) { oh -= p.OH; ++img; }
     }
   }
 #pragma unroll
@@ -486,19 +500,33 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
   __syncthreads();
   if (p.vec_store) {
     constexpr int CPR = BN / 16;
-    for (int idx = tid; idx < BM * CPR; idx += NT) {
-      const int lrow = idx / CPR, ch = idx - lrow * CPR;
-      const int grow = m0 + lrow, gcol = n0 + ch * 16;
-      if (grow < p.M && gcol < p.N) {
-        size_t orow = (size_t)grow;
-        if (p.ob > 0) {  // physically padded NHWC output: interior pixel (oh + ob, ow + ob)
-          const int P = p.OH * p.OW;
-          const int img = grow / P, rem = grow - img * P;
-          const int oh = rem / p.OW, ow = rem - oh * p.OW;
-          orow = ((size_t)img * p.OHp + oh + p.ob) * p.OWp + ow + p.ob;
+    if (AMODE == 1 && CPR == 8) {
+      // thread -> (row (tid >> 3) + NT/8 * i, chunk tid & 7): the rows of the staging map, so o_pix applies
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) {
+        const int lrow = (tid >> 3) + (NT >> 3) * i, ch = tid & 7;
+        const int grow = m0 + lrow, gcol = n0 + ch * 16;
+        if (grow < p.M && gcol < p.N) {
+          const size_t orow = p.ob > 0 ? (size_t)o_pix[i] : (size_t)grow;
+          const uint32_t* s = reinterpret_cast<const uint32_t*>(smem + lrow * SROW + ch * 16);
+          *reinterpret_cast<uint4*>(p.out + orow * p.N + gcol) = make_uint4(s[0], s[1], s[2], s[3]);
         }
-        const uint32_t* s = reinterpret_cast<const uint32_t*>(smem + lrow * SROW + ch * 16);
-        *reinterpret_cast<uint4*>(p.out + orow * p.N + gcol) = make_uint4(s[0], s[1], s[2], s[3]);
+      }
+    } else {
+      for (int idx = tid; idx < BM * CPR; idx += NT) {
+        const int lrow = idx / CPR, ch = idx - lrow * CPR;
+        const int grow = m0 + lrow, gcol = n0 + ch * 16;
+        if (grow < p.M && gcol < p.N) {
+          size_t orow = (size_t)grow;
+          if (p.ob > 0) {  // physically padded NHWC output: interior pixel (oh + ob, ow + ob)
+            const int P = p.OH * p.OW;
+            const int img = grow / P, rem = grow - img * P;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            orow = ((size_t)img * p.OHp + oh + p.ob) * p.OWp + ow + p.ob;
+          }
+          const uint32_t* s = reinterpret_cast<const uint32_t*>(smem + lrow * SROW + ch * 16);
+          *reinterpret_cast<uint4*>(p.out + orow * p.N + gcol) = make_uint4(s[0], s[1], s[2], s[3]);
+        }
       }
     }
   } else {
@@ -678,6 +706,23 @@ __global__ __launch_bounds__(256) void repack_smallc_kernel(const uint8_t* __res
   }
 }
 
+// Linear weight panel [rows][Kpad] with K reordered from the reference's flattened NCHW (c, h*w) to the
+// flattened NHWC (h*w, c) of the engine's activations; padding columns stay zero
+__global__ __launch_bounds__(256) void permute_k_kernel(const int8_t* __restrict__ B, int8_t* __restrict__ Bp,
+                                                        int64_t total, int Kpad, int K, int c, int hw) {
+  const int64_t gstride = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += gstride) {
+    const int kq = (int)(e % Kpad);
+    const int64_t row = e / Kpad;
+    int8_t v = 0;
+    if (kq < K) {
+      const int pix = kq / c, ch = kq - pix * c;
+      v = B[row * Kpad + (int64_t)ch * hw + pix];
+    }
+    Bp[e] = v;
+  }
+}
+
 // cached per (layer, s_in, zp_in): ocp = oc + 128*wsum, biasf = (float)qb / s_in
 __global__ __launch_bounds__(64) void finish_offsets_kernel(const int32_t* __restrict__ oc,
                                                             const int32_t* __restrict__ wsum,
@@ -847,7 +892,9 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   I8IE_REQUIRE(c.M > 0 && c.N > 0 && c.Kpad > 0 && c.Kpad % BK2 == 0, "igemm dimensions");
   I8IE_REQUIRE((reinterpret_cast<uintptr_t>(c.A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(c.B) & 15u) == 0,
                "operands must be 16-byte aligned");
-  if (c.a_bytes >= igemm_chunk_limit()) {
+  // (the kernel also keeps bordered-output pixel indices in 32 bits)
+  const size_t out_pixels = c.amode == 1 ? (size_t)(c.M / (c.OH * c.OW)) * (c.OH + 2 * c.ob) * (c.OW + 2 * c.ob) : 0;
+  if (c.a_bytes >= igemm_chunk_limit() || out_pixels >= ((size_t)1 << 32)) {
     const size_t limit = igemm_chunk_limit();
     const int P = c.amode == 1 ? c.OH * c.OW : 1;  // rows per unit (image / row)
     const size_t unit_in = c.amode == 1 ? (size_t)c.Hp * c.Wp * c.C : (size_t)c.lda;
@@ -856,6 +903,11 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     I8IE_REQUIRE(c.M % P == 0 && unit_in > 0 && unit_in < limit, "igemm: one image / row exceeds the offset range");
     const int units = c.M / P;
     int per = (int)((limit - 1) / unit_in);
+    if (c.amode == 1) {
+      const size_t opi = (size_t)(c.OH + 2 * ob) * (c.OW + 2 * ob);  // output pixels per image
+      const size_t cap = (((size_t)1 << 32) - 1) / opi;
+      if ((size_t)per > cap) per = (int)cap;
+    }
     if (per < 1) per = 1;
     if (c.amode == 1 && (size_t)per * unit_out % 16 != 0) per -= per % 16;  // keep 16-byte aligned sub-outputs
     if (per < 1) per = 1;
@@ -982,6 +1034,13 @@ int i8ie_launch_fill_border(i8ie_ctx* ctx, uint8_t* out, int n, int c, int h, in
   I8ieProfScope prof(ctx, "fill_border_u8", 0.0, 16.0 * total);
   fill_border_kernel<<<cap_grid(total, 256), 256, 0, ctx->stream>>>(out, total, h, w, c / 16, b,
                                                                     (uint32_t)(zp & 0xFF) * 0x01010101u);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+int i8ie_launch_permute_k(i8ie_ctx* ctx, const int8_t* B, int8_t* Bp, int rows, int Kpad, int K, int c, int hw) {
+  const int64_t total = (int64_t)rows * Kpad;
+  permute_k_kernel<<<cap_grid(total, 256), 256, 0, ctx->stream>>>(B, Bp, total, Kpad, K, c, hw);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }

@@ -30,6 +30,7 @@ int i8ie_launch_nchw_to_nhwc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int
 int i8ie_launch_nhwc_to_nchw(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int b);
 int i8ie_launch_reborder(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int ib, int ob,
                          int zp);
+int i8ie_launch_permute_k(i8ie_ctx* ctx, const int8_t* B, int8_t* Bp, int rows, int Kpad, int K, int c, int hw);
 int i8ie_launch_repack_smallc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int Hp,
                               int Wg, int ph, int pw, int zp, int rebias);
 int i8ie_launch_fill_border(i8ie_ctx* ctx, uint8_t* out, int n, int c, int h, int w, int b, int zp);
@@ -179,6 +180,8 @@ struct i8ie_layer {
   int8_t* qw = nullptr;     // [n][K] as converted, K ordered (c, kh, kw)
   int8_t* qb = nullptr;     // [n]
   int8_t* Bpack = nullptr;  // [Npad][Kpad] zero padded, reference K order (Linear; conv path F)
+  int8_t* Bperm = nullptr;  // Linear fed by an NHWC-flattened activation: Bpack with K reordered (h, w, c)
+  int perm_c = 0, perm_hw = 0;
   int path = PATH_F;        // conv: PATH_A / PATH_B / PATH_F
   int8_t* Bpack2 = nullptr; // conv paths A/B: [Npad][Kpad2], K ordered (kh, kw, c) / grouped
   int K2 = 0, Kpad2 = 0;    // valid / padded K of Bpack2 (bytes)
@@ -449,8 +452,32 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
   I8IE_TRY(ensure_offsets(L, s_in, zp_in));
 
-  if (!L->conv) {  // ---- Linear: row-major in / out, layouts do not apply -----------------------
+  if (!L->conv) {  // ---- Linear: row-major in / out -------------------------------------------------
     I8IE_REQUIRE(in_border == 0 && out_border == 0, "Linear tensors carry no border");
+    // Rows that are a flattened NHWC activation [m][h][w][c] (the engine's layout between layers) instead of
+    // the reference's flattened NCHW: same contraction with K walked in (h, w, c) order, so the weight panel
+    // is permuted once per (c, h*w) and the input is used as it lies -- no transpose back to NCHW.  oc[] and
+    // wsum[] are sums over all of K and keep the reference's accumulation order (they come from qw).
+    const int hw = (in_layout == I8IE_LAYOUT_NHWC && h > 0 && w > 0) ? h * w : 1;
+    const int8_t* panel = L->Bpack;
+    if (hw > 1) {
+      I8IE_REQUIRE(L->K % hw == 0, "Linear: in_features is not c * h * w for the given h, w");
+      if (force_fallback(ctx) || L->K % 16 != 0 || !aligned16(in)) {
+        // the any-geometry route wants reference order: transpose the input instead of the weights
+        I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->K + (size_t)m * L->Kpad + (size_t)8 * m * L->n * 4 + 4096));
+        uint8_t* t = (uint8_t*)ctx->ws + i8ie_align_up((size_t)m * L->Kpad + (size_t)8 * m * L->n * 4, 256) + 512;
+        I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, in, t, m, L->K / hw, h, w, 0));
+        return i8ie_layer_forward_fused(L, t, I8IE_LAYOUT_NCHW, 0, m, 0, 0, s_in, zp_in, relu, out, out_layout,
+                                        out_border, acc);
+      }
+      if (L->Bperm == nullptr || L->perm_c != L->K / hw || L->perm_hw != hw) {
+        if (L->Bperm == nullptr) I8IE_TRY(i8ie_malloc(ctx, (size_t)L->Npad * L->Kpad, (void**)&L->Bperm));
+        I8IE_TRY(i8ie_launch_permute_k(ctx, L->Bpack, L->Bperm, L->Npad, L->Kpad, L->K, L->K / hw, hw));
+        L->perm_c = L->K / hw;
+        L->perm_hw = hw;
+      }
+      panel = L->Bperm;
+    }
     const bool need_pad = (L->K % 16 != 0) || !aligned16(in);
     if (force_fallback(ctx)) {
       if (need_pad) I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->Kpad));
@@ -486,7 +513,7 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
     }
     c.a_bytes = (size_t)m * c.lda;
     c.amode = 0; c.M = m;
-    c.B = L->Bpack; c.Kpad = L->Kpad; c.Npad = L->Npad; c.N = L->n; c.ocp = L->ocp; c.biasf = L->biasf;
+    c.B = panel; c.Kpad = L->Kpad; c.Npad = L->Npad; c.N = L->n; c.ocp = L->ocp; c.biasf = L->biasf;
     c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
     c.out = out; c.ob = 0; c.acc = acc; c.Ktrue = L->K;
     return i8ie_igemm_launch(ctx, c);
@@ -649,6 +676,7 @@ int i8ie_layer_destroy(i8ie_layer* L) {
   i8ie_free(ctx, L->wsum);
   i8ie_free(ctx, L->oc);
   i8ie_free(ctx, L->ocp);
+  if (L->Bperm) i8ie_free(ctx, L->Bperm);
   i8ie_free(ctx, L->biasf);
   delete L;
   return I8IE_OK;

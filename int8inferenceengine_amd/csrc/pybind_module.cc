@@ -324,7 +324,9 @@ struct Tensor {
   // include/tensor.h:106-133: at most one -1, no zeros, sizes must match
   Tensor<T> reshape(std::vector<ssize_t> shp) {
     realize();
-    if (st) st->to_nchw();  // views are defined on the reference's element order
+    // Views are defined on the reference's element order.  A border-free NHWC buffer is converted only when its
+    // bytes are observed (dptr() / numpy()): a Linear layer fed by the flattened view reads it as it lies.
+    if (st && !(st->layout == I8IE_LAYOUT_NHWC && st->border == 0)) st->to_nchw();
     ssize_t midx = -1, sz = 1;
     for (size_t i = 0; i < shp.size(); ++i) {
       if (shp[i] < 0) {
@@ -544,7 +546,7 @@ Tensor<u8_t> relu_u8(Tensor<u8_t>& in) {  // src/functional.cc:15-26
     out.pend_relu = true;  // (qsrc is not carried over: relu(quantize(x)) is not a plain quantize)
     return out;
   }
-  const uint8_t* src = in.dptr_any();
+  const uint8_t* src = in.shape.size() == 4 ? in.dptr_any() : in.dptr();
   Tensor<u8_t> out(in.shape);
   out.scale = in.scale;
   out.zero_point = in.zero_point;
@@ -810,7 +812,17 @@ class BaseLayer {
             src.realize(out_layout == I8IE_LAYOUT_NHWC ? pad : 0);
             ip = src.dptr_any();
           } else {
-            ip = src.dptr();
+            src.realize(0);
+            Storage* s = src.st.get();
+            // x.reshape(n, -1) of an NHWC activation: the Linear layer walks K in (h, w, c) order instead
+            if (s && s->layout == I8IE_LAYOUT_NHWC && s->border == 0 && s->dn == m && s->dh * s->dw > 1 &&
+                (ssize_t)s->dn * s->dc * s->dh * s->dw == src.size) {
+              ip = src.dptr_any();
+              h = s->dh;
+              w = s->dw;
+            } else {
+              ip = src.dptr();
+            }
           }
           const int in_layout = src.st->layout, in_border = src.st->border;
           const int ob = out_layout == I8IE_LAYOUT_NHWC ? border : 0;

@@ -263,9 +263,11 @@ class Ctx:
         return p
 
     def layer_forward_fused(self, kind, q_in_nchw, qw, qb, s_in, zp_in, s_w, s_out, zp_out, stride=1, pad=0,
-                            in_nhwc=False, out_nhwc=False, relu=False, want_acc=True, in_border=0, out_border=0):
+                            in_nhwc=False, out_nhwc=False, relu=False, want_acc=True, in_border=0, out_border=0,
+                            flat_chw=None):
         """i8ie_layer_forward_fused.  Input is given in NCHW and laid out on the host as asked (NHWC with a
-        zero-point border when in_nhwc); the output is returned in NCHW together with the raw physical array."""
+        zero-point border when in_nhwc); the output is returned in NCHW together with the raw physical array.
+        Linear with flat_chw=(c, h, w) and in_nhwc: the [m][c*h*w] rows are handed over as flattened NHWC."""
         q_in = np.ascontiguousarray(q_in_nchw, np.uint8)
         qw = np.ascontiguousarray(qw, np.int8)
         qb = np.ascontiguousarray(qb, np.int8)
@@ -277,6 +279,9 @@ class Ctx:
                                         C.c_float(s_w), C.byref(L)))
             oshape, ashape, h, w = (m, n), (m, n), 0, 0
             phys_in = q_in
+            if flat_chw is not None and in_nhwc:
+                cc, h, w = flat_chw
+                phys_in = np.ascontiguousarray(q_in.reshape(m, cc, h, w).transpose(0, 2, 3, 1)).reshape(m, k)
         else:
             m, c, h, w = q_in.shape
             kc, _, kh, kw = qw.shape

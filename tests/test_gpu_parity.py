@@ -393,3 +393,24 @@ print("chunked ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "chunked ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("mchw_n", [(37, 256, 6, 6, 300), (5, 32, 3, 5, 10), (130, 16, 2, 2, 64), (9, 10, 3, 3, 7)])
+@pytest.mark.parametrize("fallback", [False, True])
+def test_linear_reads_flattened_nhwc_rows(gpu, orc, mchw_n, fallback):
+    """x.reshape(n, -1) of an NHWC activation fed to a Linear layer: the layer permutes its weight panel once
+    and reads the rows as they lie; accumulators and outputs equal the reference's flattened-NCHW result.
+    (c*h*w = 90 is not a multiple of 16 and the forced fallback transposes the input instead.)"""
+    m, c, h, w, n = mchw_n
+    cs = synth.linear_case(orc, 300 + sum(mchw_n), m, c * h * w, n)
+    gpu.set_force_fallback(fallback)
+    try:
+        for relu in (False, True):
+            out, acc, _ = gpu.layer_forward_fused("linear", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"],
+                                                  cs["s_w"], cs["s_out"], cs["zp_out"], in_nhwc=True, relu=relu,
+                                                  flat_chw=(c, h, w))
+            want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
+            assert np.array_equal(acc, cs["acc"])
+            assert np.array_equal(out, want)
+    finally:
+        gpu.set_force_fallback(False)
