@@ -207,6 +207,15 @@ int i8ie_layer_get_output_qparams(const i8ie_layer* layer, float* s_out, uint8_t
  * h, w are ignored for Linear.  acc_dbg_dev as in the stateless calls.       */
 int i8ie_layer_forward(i8ie_layer* layer, const uint8_t* in_dev, int m, int h, int w, float s_in,
                        uint8_t zp_in, uint8_t* out_dev, int32_t* acc_dbg_dev);
+/* dequantize(linear(x)): src/quantize_utils.cc:54-58 applied to the result of Linear::forward_prop(u8)
+ * (src/fully_connected.cc:22-52), in one call.  Layers with at most 16 output features (classifier heads)
+ * run a fused kernel -- one wavefront per input row, v_dot4_i32_i8 over K, wavefront reduction, the
+ * reference's bias/requant epilogue and the dequantize -- and may pass out_u8 = NULL; any other Linear
+ * layer runs its ordinary forward into out_u8 (required) followed by the dequantize kernel.
+ * in_layout / h / w as for i8ie_layer_forward_fused. */
+int i8ie_layer_forward_dequant(i8ie_layer* layer, const uint8_t* in_dev, int in_layout, int m, int h, int w,
+                               float s_in, uint8_t zp_in, int relu, uint8_t* out_u8_dev, float* out_f32_dev);
+
 /* Same computation with the layout conversions and the following relu<u8>
  * (src/functional.cc:15-26: out = max(out, zp_out)) folded in.  in/out may each be NCHW or
  * NHWC; an NHWC tensor may carry a physical border of `border` pixels on each side of H and W

@@ -706,6 +706,94 @@ __global__ __launch_bounds__(256) void repack_smallc_kernel(const uint8_t* __res
   }
 }
 
+// ---- Linear with a handful of output features (the classifier head: fc8, N = 10) ------------------------
+// One wave per input row: every lane walks K in 16-byte chunks (chunk = lane, lane + 64, ...), v_dot4_i32_i8
+// against the N weight rows (the panel is a few tens of KB: L1/L2 resident for every wave), a wavefront
+// butterfly sums the 64 partial dot products, lane j finishes feature j with the reference's Linear epilogue
+// (src/fully_connected.cc:42-48: + oc, + (float)q_b / s_in in float, truncate, down_scale) and, when asked,
+// the dequantize that follows it in every network (src/quantize_utils.cc:54-58).  Replaces a 128 x 32 MFMA
+// tile launch that is 92 % padding, its split-K reduction and the separate dequantize launch.
+constexpr int kSmallN = 16;
+
+struct SmallNArgs {
+  const uint8_t* A;
+  size_t lda;
+  int M, K;          // K % 16 == 0
+  const int8_t* B;   // [>= N][Kpad], K order matching A, zero padded
+  int Kpad, N;
+  const int32_t* ocp;  // oc + 128 * wsum
+  const float* biasf;
+  Requant rq;
+  int relu_lo;
+  uint8_t* out;      // [M][N] or nullptr
+  int32_t* acc;      // [M][N] or nullptr (pre-bias INT32 accumulators)
+  float* out_f32;    // [M][N] or nullptr: (q - zp_out) * s_out
+  float dq_scale;
+  int dq_zp;
+};
+
+// WPR = waves per row: 1 (four rows per block) for short K, 4 (one row per block, K split over 256 threads
+// and the four partial sums joined through LDS) when K is long enough to make one wave's walk a latency chain
+template <int WPR>
+__global__ __launch_bounds__(256) void linear_smalln_kernel(SmallNArgs p) {
+  __shared__ int part[4][kSmallN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = WPR == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+  const bool live = row < p.M;
+  int sum[kSmallN];
+#pragma unroll
+  for (int j = 0; j < kSmallN; ++j) sum[j] = 0;
+  if (live) {
+    const uint8_t* arow = p.A + (size_t)row * p.lda;
+    const int t = WPR == 1 ? lane : (int)threadIdx.x;
+    for (int k0 = t * 16; k0 < p.K; k0 += 64 * WPR * 16) {
+      const v4i a = *reinterpret_cast<const v4i*>(arow + k0) ^ (int)0x80808080;  // u8 -> s8 (128 * wsum is in ocp)
+#pragma unroll
+      for (int j = 0; j < kSmallN; ++j) {
+        if (j < p.N) {
+          const v4i wv = *reinterpret_cast<const v4i*>(p.B + (size_t)j * p.Kpad + k0);
+          int acc = sum[j];
+          acc = __builtin_amdgcn_sdot4(a.x, wv.x, acc, false);
+          acc = __builtin_amdgcn_sdot4(a.y, wv.y, acc, false);
+          acc = __builtin_amdgcn_sdot4(a.z, wv.z, acc, false);
+          acc = __builtin_amdgcn_sdot4(a.w, wv.w, acc, false);
+          sum[j] = acc;
+        }
+      }
+    }
+  }
+  // wavefront reduction (integer adds: any order is exact)
+#pragma unroll
+  for (int j = 0; j < kSmallN; ++j) {
+    if (j < p.N) {
+      int v = sum[j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      sum[j] = v;
+    }
+  }
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < kSmallN; ++j)
+    if (lane == j) c = sum[j];
+  if (WPR > 1) {
+    if (lane < kSmallN) part[wave][lane] = c;
+    __syncthreads();
+    if (wave != 0) return;
+    c = 0;
+    if (lane < kSmallN) c = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  }
+  if (live && lane < p.N) {
+    c += p.ocp[lane];
+    const size_t o = (size_t)row * p.N + lane;
+    if (p.acc) p.acc[o] = c;
+    c = (int)((float)c + p.biasf[lane]);  // src/fully_connected.cc:44
+    const int q = requant_exact((float)c, p.rq, p.relu_lo);
+    if (p.out) p.out[o] = (uint8_t)q;
+    if (p.out_f32) p.out_f32[o] = (float)(q - p.dq_zp) * p.dq_scale;  // src/quantize_utils.cc:38-42
+  }
+}
+
 // Linear weight panel [rows][Kpad] with K reordered from the reference's flattened NCHW (c, h*w) to the
 // flattened NHWC (h*w, c) of the engine's activations; padding columns stay zero
 __global__ __launch_bounds__(256) void permute_k_kernel(const int8_t* __restrict__ B, int8_t* __restrict__ Bp,
@@ -1034,6 +1122,40 @@ int i8ie_launch_fill_border(i8ie_ctx* ctx, uint8_t* out, int n, int c, int h, in
   I8ieProfScope prof(ctx, "fill_border_u8", 0.0, 16.0 * total);
   fill_border_kernel<<<cap_grid(total, 256), 256, 0, ctx->stream>>>(out, total, h, w, c / 16, b,
                                                                     (uint32_t)(zp & 0xFF) * 0x01010101u);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+struct I8ieSmallNCall {
+  const uint8_t* A;
+  size_t lda;
+  int M, K;
+  const int8_t* B;
+  int Kpad, N;
+  const int32_t* ocp;
+  const float* biasf;
+  float s_in, s_w, s_out;
+  int zp_out, relu;
+  uint8_t* out;
+  int32_t* acc;
+  float* out_f32;
+};
+int i8ie_smalln_max_features() { return kSmallN; }
+int i8ie_launch_linear_smalln(i8ie_ctx* ctx, const I8ieSmallNCall& c) {
+  I8IE_REQUIRE(c.M > 0 && c.N > 0 && c.N <= kSmallN && c.K > 0 && c.K % 16 == 0 && c.lda % 16 == 0, "small-N linear shape");
+  I8IE_REQUIRE((reinterpret_cast<uintptr_t>(c.A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(c.B) & 15u) == 0,
+               "operands must be 16-byte aligned");
+  SmallNArgs a{};
+  a.A = c.A; a.lda = c.lda; a.M = c.M; a.K = c.K; a.B = c.B; a.Kpad = c.Kpad; a.N = c.N;
+  a.ocp = c.ocp; a.biasf = c.biasf;
+  a.rq.sa = c.s_in; a.rq.sb = c.s_w; a.rq.sc = c.s_out; a.rq.zpf = (float)c.zp_out; a.rq.ms = 0.0f; a.rq.fast = 0;
+  a.relu_lo = c.relu ? c.zp_out : 0;
+  a.out = c.out; a.acc = c.acc; a.out_f32 = c.out_f32; a.dq_scale = c.s_out; a.dq_zp = c.zp_out;
+  I8ieProfScope prof(ctx, "linear_smalln_dot4", 2.0 * c.M * c.N * c.K, (double)c.M * c.K + (double)c.N * c.K + 5.0 * c.M * c.N);
+  if (c.K >= 2048)
+    linear_smalln_kernel<4><<<c.M, 256, 0, ctx->stream>>>(a);
+  else
+    linear_smalln_kernel<1><<<(c.M + 3) / 4, 256, 0, ctx->stream>>>(a);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }

@@ -31,6 +31,22 @@ int i8ie_launch_nhwc_to_nchw(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int
 int i8ie_launch_reborder(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int ib, int ob,
                          int zp);
 int i8ie_launch_permute_k(i8ie_ctx* ctx, const int8_t* B, int8_t* Bp, int rows, int Kpad, int K, int c, int hw);
+struct I8ieSmallNCall {
+  const uint8_t* A;
+  size_t lda;
+  int M, K;
+  const int8_t* B;
+  int Kpad, N;
+  const int32_t* ocp;
+  const float* biasf;
+  float s_in, s_w, s_out;
+  int zp_out, relu;
+  uint8_t* out;
+  int32_t* acc;
+  float* out_f32;
+};
+int i8ie_smalln_max_features();
+int i8ie_launch_linear_smalln(i8ie_ctx* ctx, const I8ieSmallNCall& c);
 int i8ie_launch_repack_smallc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int Hp,
                               int Wg, int ph, int pw, int zp, int rebias);
 int i8ie_launch_fill_border(i8ie_ctx* ctx, uint8_t* out, int n, int c, int h, int w, int b, int zp);
@@ -437,10 +453,34 @@ int i8ie_layer_padding(const i8ie_layer* L, int* pad) {
   return I8IE_OK;
 }
 
+static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, int in_border, int m, int h, int w,
+                              float s_in, uint8_t zp_in, int relu, uint8_t* out, int out_layout, int out_border,
+                              int32_t* acc, float* out_f32);
+
 int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, int in_border, int m, int h, int w,
                              float s_in, uint8_t zp_in, int relu, uint8_t* out, int out_layout, int out_border,
                              int32_t* acc) {
-  I8IE_REQUIRE(L && in && out, "null argument");
+  I8IE_REQUIRE(out != nullptr, "null argument");
+  return layer_forward_impl(L, in, in_layout, in_border, m, h, w, s_in, zp_in, relu, out, out_layout, out_border, acc,
+                            nullptr);
+}
+
+// dequantize(layer(x)) for a Linear layer: src/quantize_utils.cc:54-58 applied to the result of
+// src/fully_connected.cc:22-52.  out_u8 may be null when the layer has at most 16 output features (the fused
+// small-N kernel writes the FP32 values directly); otherwise it receives the u8 result as usual.
+int i8ie_layer_forward_dequant(i8ie_layer* L, const uint8_t* in, int in_layout, int m, int h, int w, float s_in,
+                               uint8_t zp_in, int relu, uint8_t* out_u8, float* out_f32) {
+  I8IE_REQUIRE(L && out_f32, "null argument");
+  I8IE_REQUIRE(!L->conv, "i8ie_layer_forward_dequant: Linear layers only");
+  return layer_forward_impl(L, in, in_layout, 0, m, h, w, s_in, zp_in, relu, out_u8, I8IE_LAYOUT_NCHW, 0, nullptr,
+                            out_f32);
+}
+
+static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, int in_border, int m, int h, int w,
+                              float s_in, uint8_t zp_in, int relu, uint8_t* out, int out_layout, int out_border,
+                              int32_t* acc, float* out_f32) {
+  I8IE_REQUIRE(L && in, "null argument");
+  I8IE_REQUIRE(out != nullptr || (out_f32 != nullptr && !L->conv), "null output");
   I8IE_REQUIRE(m > 0, "non-positive batch");
   I8IE_REQUIRE((in_layout == I8IE_LAYOUT_NCHW || in_layout == I8IE_LAYOUT_NHWC) &&
                    (out_layout == I8IE_LAYOUT_NCHW || out_layout == I8IE_LAYOUT_NHWC),
@@ -467,8 +507,8 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
         I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->K + (size_t)m * L->Kpad + (size_t)8 * m * L->n * 4 + 4096));
         uint8_t* t = (uint8_t*)ctx->ws + i8ie_align_up((size_t)m * L->Kpad + (size_t)8 * m * L->n * 4, 256) + 512;
         I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, in, t, m, L->K / hw, h, w, 0));
-        return i8ie_layer_forward_fused(L, t, I8IE_LAYOUT_NCHW, 0, m, 0, 0, s_in, zp_in, relu, out, out_layout,
-                                        out_border, acc);
+        return layer_forward_impl(L, t, I8IE_LAYOUT_NCHW, 0, m, 0, 0, s_in, zp_in, relu, out, out_layout, out_border,
+                                  acc, out_f32);
       }
       if (L->Bperm == nullptr || L->perm_c != L->K / hw || L->perm_hw != hw) {
         if (L->Bperm == nullptr) I8IE_TRY(i8ie_malloc(ctx, (size_t)L->Npad * L->Kpad, (void**)&L->Bperm));
@@ -479,6 +519,19 @@ int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, in
       panel = L->Bperm;
     }
     const bool need_pad = (L->K % 16 != 0) || !aligned16(in);
+    if (!force_fallback(ctx) && !need_pad && L->n <= i8ie_smalln_max_features()) {
+      // classifier head: one wave per row, dot4 + wavefront reduction, epilogue (and dequantize) fused
+      I8ieSmallNCall sc{};
+      sc.A = in; sc.lda = (size_t)L->K; sc.M = m; sc.K = L->K; sc.B = panel; sc.Kpad = L->Kpad; sc.N = L->n;
+      sc.ocp = L->ocp; sc.biasf = L->biasf; sc.s_in = s_in; sc.s_w = L->s_w; sc.s_out = L->s_out;
+      sc.zp_out = L->zp_out; sc.relu = relu; sc.out = out; sc.acc = acc; sc.out_f32 = out_f32;
+      return i8ie_launch_linear_smalln(ctx, sc);
+    }
+    I8IE_REQUIRE(out != nullptr, "i8ie_layer_forward_dequant: this layer needs the u8 output buffer as well");
+    if (out_f32 != nullptr) {  // general shape: the ordinary forward, then the dequantize kernel
+      I8IE_TRY(layer_forward_impl(L, in, in_layout, 0, m, h, w, s_in, zp_in, relu, out, I8IE_LAYOUT_NCHW, 0, acc, nullptr));
+      return i8ie_dequantize_u8_f32(ctx, out, out_f32, (int64_t)m * L->n, L->s_out, L->zp_out);
+    }
     if (force_fallback(ctx)) {
       if (need_pad) I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->Kpad));
       I8IE_TRY(linear_run_v1(ctx, in, m, L->K, L->Bpack, L->Kpad, L->qb, L->n, L->oc, L->wsum, s_in, L->s_w, L->s_out,

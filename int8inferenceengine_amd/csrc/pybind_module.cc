@@ -281,6 +281,8 @@ struct Tensor {
   // arguments: fuse relu; physical border wanted by the consumer (honoured for NHWC results)
   std::shared_ptr<std::function<std::shared_ptr<Storage>(bool, int)>> pend;
   bool pend_relu = false;
+  // a pending small Linear layer can also produce dequantize(layer(x)) directly (argument: fuse relu)
+  std::shared_ptr<std::function<std::shared_ptr<Storage>(bool)>> pend_f32;
   // set while this tensor is a not-yet-launched quantize(x, scale, zp): lets the first conv read x directly
   std::shared_ptr<Storage> qsrc;
   float qscale = 0;
@@ -290,6 +292,7 @@ struct Tensor {
     if (!pend) return;
     st = (*pend)(pend_relu, border);
     pend.reset();
+    pend_f32.reset();
     qsrc.reset();
   }
 
@@ -529,6 +532,13 @@ Tensor<u8_t> quantize(Tensor<float>& in, float scale, u8_t zp) {  // src/quantiz
   return out;
 }
 Tensor<float> dequantize(Tensor<u8_t>& in) {  // src/quantize_utils.cc:54-58
+  if (in.pend && in.pend_f32) {  // classifier head still pending: layer + (relu) + dequantize in one launch
+    Tensor<float> out;
+    out.shape = in.shape;
+    out.size = in.size;
+    out.st = (*in.pend_f32)(in.pend_relu);
+    return out;
+  }
   Tensor<float> out(in.shape);
   check(i8ie_dequantize_u8_f32(ctx(), in.dptr(), out.dptr(), in.size, in.scale, in.zero_point));
   return out;
@@ -543,6 +553,7 @@ Tensor<u8_t> relu_u8(Tensor<u8_t>& in) {  // src/functional.cc:15-26
     out.scale = in.scale;
     out.zero_point = in.zero_point;
     out.pend = in.pend;
+    out.pend_f32 = in.pend_f32;
     out.pend_relu = true;  // (qsrc is not carried over: relu(quantize(x)) is not a plain quantize)
     return out;
   }
@@ -832,6 +843,32 @@ class BaseLayer {
           src = Tensor<u8_t>();  // release the input as soon as the launch is queued
           return st;
         });
+    if (!spatial && out.shape.size() == 2 && out.shape[1] <= 16) {
+      // dequantize(layer(x)) of a classifier head: one fused launch (i8ie_layer_forward_dequant)
+      Tensor<u8_t> src2 = in;
+      out.pend_f32 = std::make_shared<std::function<std::shared_ptr<Storage>(bool)>>(
+          [handle, src2, s_in, zp_in, m, obytes](bool relu) mutable {
+            src2.realize(0);
+            Storage* s = src2.st.get();
+            const uint8_t* ip;
+            int lay = I8IE_LAYOUT_NCHW, hh = 0, ww = 0;
+            if (s && s->layout == I8IE_LAYOUT_NHWC && s->border == 0 && s->dn == m && s->dh * s->dw > 1 &&
+                (ssize_t)s->dn * s->dc * s->dh * s->dw == src2.size) {
+              ip = src2.dptr_any();
+              lay = I8IE_LAYOUT_NHWC;
+              hh = s->dh;
+              ww = s->dw;
+            } else {
+              ip = src2.dptr();
+            }
+            auto f = device_storage(obytes * sizeof(float));
+            auto q = device_storage(obytes);  // u8 side output: only written when the fused kernel does not apply
+            check(i8ie_layer_forward_dequant(handle.get(), ip, lay, m, hh, ww, s_in, zp_in, relu ? 1 : 0,
+                                             (uint8_t*)q->dev, (float*)f->dev));
+            src2 = Tensor<u8_t>();
+            return f;
+          });
+    }
     return out;
   }
   void need_quantized() const {

@@ -414,3 +414,62 @@ def test_linear_reads_flattened_nhwc_rows(gpu, orc, mchw_n, fallback):
             assert np.array_equal(out, want)
     finally:
         gpu.set_force_fallback(False)
+
+
+@pytest.mark.parametrize("mkn", [(125, 4096, 10), (1, 64, 1), (33, 1024, 16), (7, 784 // 16 * 16, 10), (300, 9216, 3)])
+def test_linear_small_n_head_and_fused_dequantize(gpu, orc, mkn):
+    """Classifier heads (N <= 16) run one wave per row with v_dot4_i32_i8 + a wavefront reduction; the INT32
+    accumulators, the u8 outputs and the fused dequantize(layer(x)) all equal the oracle's sequence."""
+    import ctypes as C
+
+    m, k, n = mkn
+    cs = synth.linear_case(orc, 900 + m + k + n, m, k, n)
+    for relu in (False, True):
+        out, acc, _ = gpu.layer_forward_fused("linear", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"],
+                                              cs["s_w"], cs["s_out"], cs["zp_out"], relu=relu)
+        want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
+        assert np.array_equal(acc, cs["acc"])
+        assert np.array_equal(out, want)
+    # dequantize(linear(x)) in one call, with and without the u8 side output
+    lib = abi.lib()
+    L = C.c_void_p()
+    qw, qb = np.ascontiguousarray(cs["qw"]), np.ascontiguousarray(cs["qb"])
+    abi.ck(lib.i8ie_linear_create(gpu.h, qw.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p), n, k,
+                                  C.c_float(cs["s_w"]), C.byref(L)))
+    abi.ck(lib.i8ie_layer_set_output_qparams(L, C.c_float(cs["s_out"]), C.c_uint8(cs["zp_out"])))
+    di = gpu.put(cs["q_in"])
+    o8, of = gpu.empty((m, n), np.uint8), gpu.empty((m, n), np.float32)
+    want_f = orc.dequantize(cs["out"], cs["s_out"], cs["zp_out"])
+    for with_u8 in (False, True):
+        abi.ck(lib.i8ie_layer_forward_dequant(L, di.ptr, 0, m, 0, 0, C.c_float(cs["s_in"]), C.c_uint8(cs["zp_in"]), 0,
+                                              o8.ptr if with_u8 else None, of.ptr))
+        assert np.array_equal(of.get().view(np.uint32), want_f.view(np.uint32))
+        if with_u8:
+            assert np.array_equal(o8.get(), cs["out"])
+    lib.i8ie_layer_destroy(L)
+    for d in (di, o8, of):
+        d.free()
+
+
+def test_forward_dequant_general_linear_needs_u8_buffer(gpu, orc):
+    import ctypes as C
+
+    cs = synth.linear_case(orc, 77, 9, 64, 40)  # 40 features: ordinary forward + dequantize kernel
+    lib = abi.lib()
+    L = C.c_void_p()
+    abi.ck(lib.i8ie_linear_create(gpu.h, cs["qw"].ctypes.data_as(C.c_void_p), cs["qb"].ctypes.data_as(C.c_void_p), 40,
+                                  64, C.c_float(cs["s_w"]), C.byref(L)))
+    abi.ck(lib.i8ie_layer_set_output_qparams(L, C.c_float(cs["s_out"]), C.c_uint8(cs["zp_out"])))
+    di = gpu.put(cs["q_in"])
+    o8, of = gpu.empty((9, 40), np.uint8), gpu.empty((9, 40), np.float32)
+    rc = lib.i8ie_layer_forward_dequant(L, di.ptr, 0, 9, 0, 0, C.c_float(cs["s_in"]), C.c_uint8(cs["zp_in"]), 0, None,
+                                        of.ptr)
+    assert rc == -1 and b"u8 output buffer" in lib.i8ie_last_error()
+    abi.ck(lib.i8ie_layer_forward_dequant(L, di.ptr, 0, 9, 0, 0, C.c_float(cs["s_in"]), C.c_uint8(cs["zp_in"]), 0,
+                                          o8.ptr, of.ptr))
+    assert np.array_equal(o8.get(), cs["out"])
+    assert np.array_equal(of.get().view(np.uint32),
+                          orc.dequantize(cs["out"], cs["s_out"], cs["zp_out"]).view(np.uint32))
+    lib.i8ie_layer_destroy(L)
+    for d in (di, o8, of):
+        d.free()
