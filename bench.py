@@ -279,6 +279,10 @@ def main():
         "launches_per_step": mfma[dom]["launches"] / args.steps,
         "launches_timed": d["launches"], "timed_in": "the timed region (every 5th contraction launch bracketed)" if prof else "untimed pass",
         "avg_launch_ms_untimed_pass_all_launches": round(mfma[dom]["ms"] / mfma[dom]["launches"], 4),
+        # context, not the contract's peak: what register-only int8 MFMA sustains on this chip when the operands
+        # toggle (tools/mfma_peak.hip k4; constant operands reach 4400-4900): profiles/r01h_mfma_peak_and_power.txt
+        "sustained_mfma_only_tops": {"random_operands": 3400.0, "constant_operands": 4860.0},
+        "frac_of_sustained_random_operand_rate": round(achieved / 3400.0, 4),
     }
     total_dev_ms = sum(v["ms"] for v in kernels.values())
     breakdown = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}

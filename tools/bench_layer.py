@@ -41,6 +41,8 @@ def main():
         n, c, h, w, kc, k, stride, pad = LAYERS[name]
         oh, ow = (h - k + 2 * pad) // stride + 1, (w - k + 2 * pad) // stride + 1
         qw = rng.integers(-63, 64, (kc, c, k, k)).astype(np.int8)
+        if os.environ.get("I8IE_BENCH_CONST"):  # constant operands: how much of the rate is data-dependent power?
+            qw[...] = 1
         qb = rng.integers(-63, 64, kc).astype(np.int8)
         L = C.c_void_p()
         abi.ck(lib.i8ie_conv2d_create(g.h, qw.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p), kc, c, k, k,
@@ -52,6 +54,8 @@ def main():
         else:
             x = rng.integers(0, 256, (n, c, h, w), dtype=np.uint8)
             layout, border = 0, 0
+        if os.environ.get("I8IE_BENCH_CONST"):
+            x[...] = 129
         di = g.put(x)
         out = g.empty((n, oh, ow, kc), np.uint8)
         ops = 2.0 * n * oh * ow * kc * c * k * k

@@ -17,9 +17,29 @@
 // build: hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o tools/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+
+// source buffers hold pseudo-random bytes by default: constant operands let the clock run ~30 % higher
+// (see k4), which flatters every structure that streams them.  MFMA_PEAK_CONST=1 restores memset(1).
+__global__ void fill_random(unsigned* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + 977u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = h;
+  }
+}
+static void fill_source(unsigned char* g, size_t bytes) {
+  if (getenv("MFMA_PEAK_CONST")) {
+    hipMemset(g, 1, bytes);
+  } else {
+    fill_random<<<1024, 256>>>(reinterpret_cast<unsigned*>(g), bytes / 4);
+    hipDeviceSynchronize();
+  }
+}
+
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(int iters, int* out, const unsigned char* gsrc) {
@@ -217,7 +237,7 @@ void run2(const char* name) {
   const int blocks = 256, iters = 2000;
   hipMalloc(&out, blocks * 256 * 4);
   hipMalloc(&gsrc, 256 * 65536 + 65536);
-  hipMemset(gsrc, 1, 256 * 65536 + 65536);
+  fill_source(gsrc, 256 * 65536 + 65536);
   const int lds = 2 * 512 * 144;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k2<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1;
@@ -239,7 +259,7 @@ void run2(const char* name) {
 }
 
 // ---- structure sweep: 4 waves (2 x 2), wave tile TM x TN MFMA tiles, LDS-DMA staging, NST stages ----------
-template <int TM, int TN, int NST>
+template <int TM, int TN, int NST, bool BUF = false, bool XORA = false>
 __global__ __launch_bounds__(256) void k3(int iters, int* out, const unsigned char* gsrc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ROWS = 64 * (TM + TN);   // A rows + B rows of the block tile
@@ -264,6 +284,8 @@ __global__ __launch_bounds__(256) void k3(int iters, int* out, const unsigned ch
     brd[ks] = (2 * TM * 32 + wn * TN * 32 + (lane & 31)) * 128 + sw;
   }
   const unsigned char* gp = gsrc + (size_t)(blockIdx.x & 255) * 65536 + tid * 16;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(gsrc), 0, 256 * 65536 + 65536, 0x00020000);
+  const int voff = (blockIdx.x & 255) * 65536 + tid * 16;
   for (int it = 0; it < iters; ++it) {
     const unsigned char* cur = smem + (NST == 2 ? (it & 1) * STAGE : 0);
     unsigned char* nxt = smem + (NST == 2 ? ((it & 1) ^ 1) * STAGE : 0);
@@ -271,7 +293,10 @@ __global__ __launch_bounds__(256) void k3(int iters, int* out, const unsigned ch
     for (int ks = 0; ks < 4; ++ks) {
       v4i a[TM], b[TN];
 #pragma unroll
-      for (int m = 0; m < TM; ++m) a[m] = *reinterpret_cast<const v4i*>(cur + ard[ks] + m * 4096);
+      for (int m = 0; m < TM; ++m) {
+        a[m] = *reinterpret_cast<const v4i*>(cur + ard[ks] + m * 4096);
+        if (XORA) a[m] = a[m] ^ (int)0x80808080;
+      }
 #pragma unroll
       for (int n = 0; n < TN; ++n) b[n] = *reinterpret_cast<const v4i*>(cur + brd[ks] + n * 4096);
 #pragma unroll
@@ -280,9 +305,14 @@ __global__ __launch_bounds__(256) void k3(int iters, int* out, const unsigned ch
         for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[n], a[m], acc[m][n], 0, 0, 0);
       if (NST == 2) {
 #pragma unroll
-        for (int i = ks * NDMA / 4; i < (ks + 1) * NDMA / 4; ++i)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + ((it * NDMA + i) & 15) * 4096),
-                                           (__attribute__((address_space(3))) void*)(nxt + wave * 1024 + i * 4096), 16, 0, 0);
+        for (int i = ks * NDMA / 4; i < (ks + 1) * NDMA / 4; ++i) {
+          if (BUF)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(nxt + wave * 1024 + i * 4096), 16,
+                                                     voff + ((it * NDMA + i) & 15) * 4096, 0, 0, 0);
+          else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + ((it * NDMA + i) & 15) * 4096),
+                                             (__attribute__((address_space(3))) void*)(nxt + wave * 1024 + i * 4096), 16, 0, 0);
+        }
       }
     }
     if (NST == 1) {
@@ -304,35 +334,91 @@ __global__ __launch_bounds__(256) void k3(int iters, int* out, const unsigned ch
   out[blockIdx.x * 256 + tid] = s;
 }
 
-template <int TM, int TN, int NST>
+template <int TM, int TN, int NST, bool BUF = false, bool XORA = false>
 void run3(int blocks_per_cu) {
   int* out;
   unsigned char* gsrc;
   const int blocks = 256 * blocks_per_cu, iters = 2000;
   hipMalloc(&out, blocks * 256 * 4);
   hipMalloc(&gsrc, 256 * 65536 + 65536);
-  hipMemset(gsrc, 1, 256 * 65536 + 65536);
+  fill_source(gsrc, 256 * 65536 + 65536);
   const int lds = NST * 64 * (TM + TN) * 128;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k3<TM, TN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k3<TM, TN, NST, BUF, XORA>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   int occ = 0;
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k3<TM, TN, NST>, 256, lds);
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k3<TM, TN, NST, BUF, XORA>, 256, lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  k3<TM, TN, NST><<<blocks, 256, lds>>>(200, out, gsrc);
+  k3<TM, TN, NST, BUF, XORA><<<blocks, 256, lds>>>(200, out, gsrc);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k3<TM, TN, NST><<<blocks, 256, lds>>>(iters, out, gsrc);
+  k3<TM, TN, NST, BUF, XORA><<<blocks, 256, lds>>>(iters, out, gsrc);
   hipEventRecord(e1);
   hipDeviceSynchronize();
   hipError_t err = hipGetLastError();
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
   const double ops = (double)blocks * 4 * iters * 4 * TM * TN * 65536.0;
-  printf("DMA sweep: wave tile %dx%d (block %dx%d) stages %d launched %d/CU (occupancy %d): %.3f ms  %.0f TOPS  (%s)\n", TM, TN,
+  printf("DMA sweep%s%s: wave tile %dx%d (block %dx%d) stages %d launched %d/CU (occupancy %d): %.3f ms  %.0f TOPS  (%s)\n", BUF ? " [buffer_load lds]" : "", XORA ? " [xor A]" : "", TM, TN,
          TM * 64, TN * 64, NST, blocks_per_cu, occ, ms, ops / (ms * 1e-3) / 1e12, hipGetErrorString(err));
   hipFree(out);
   hipFree(gsrc);
+}
+
+// ---- register-only MFMA rate as a function of operand toggling (sustained clock under power limits) ---------
+//   RANDOM = false: every MFMA multiplies the same two constant fragments
+//   RANDOM = true : eight pseudo-random A and B fragments, rotated every instruction
+template <bool RANDOM>
+__global__ __launch_bounds__(256) void k4(int iters, int* out) {
+  const int tid = threadIdx.x + blockIdx.x * 256;
+  v16i acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+  v4i ap[8], bp[8];
+  unsigned h = tid * 2654435761u + 12345u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      h = h * 1664525u + 1013904223u;
+      ap[i][q] = RANDOM ? (int)h : 0x01010101;
+      h = h * 1664525u + 1013904223u;
+      bp[i][q] = RANDOM ? (int)h : 0x01010101;
+    }
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bp[u], ap[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bp[(u + 1) & 7], ap[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bp[u], ap[(u + 3) & 7], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bp[(u + 5) & 7], ap[(u + 2) & 7], acc[1][1], 0, 0, 0);
+    }
+  }
+  int s = 0;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  out[tid] = s;
+}
+
+template <bool RANDOM>
+void run4(int blocks_per_cu, int iters) {
+  int* out;
+  const int blocks = 256 * blocks_per_cu;
+  hipMalloc(&out, blocks * 256 * 4);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  k4<RANDOM><<<blocks, 256>>>(iters / 10, out);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k4<RANDOM><<<blocks, 256>>>(iters, out);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double ops = (double)blocks * 4 * iters * 32 * 65536.0;
+  printf("register-only MFMA, %s operands, %d blocks/CU, %.1f ms run: %.0f TOPS\n", RANDOM ? "random" : "constant", blocks_per_cu, ms,
+         ops / (ms * 1e-3) / 1e12);
+  hipFree(out);
 }
 
 template <int MODE>
@@ -342,7 +428,7 @@ void run(const char* name, int blocks_per_cu) {
   const int blocks = 256 * blocks_per_cu, iters = 2000;
   hipMalloc(&out, blocks * 256 * 4);
   hipMalloc(&gsrc, 256 * 65536 + 65536);
-  hipMemset(gsrc, 1, 256 * 65536 + 65536);
+  fill_source(gsrc, 256 * 65536 + 65536);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -361,6 +447,12 @@ void run(const char* name, int blocks_per_cu) {
 }
 
 int main() {
+  run4<false>(2, 4000);
+  run4<true>(2, 4000);
+  run4<false>(2, 40000);
+  run4<true>(2, 40000);
+  run4<true>(1, 40000);
+
   for (int b = 1; b <= 2; ++b) {
     run<0>("mfma only", b);
     run<1>("mfma + lds frag reads", b);
@@ -378,6 +470,10 @@ int main() {
   run2<1>("global loads + ds_write");
   run2<2>("LDS-DMA");
   run3<4, 4, 2>(1);
+  run3<4, 4, 2, true, false>(1);
+  run3<4, 4, 2, false, true>(1);
+  run3<4, 4, 2, true, true>(1);
+  run3<4, 3, 2, true, true>(1);
   run3<4, 4, 1>(1);
   run3<4, 3, 2>(1);
   run3<4, 2, 2>(1);
