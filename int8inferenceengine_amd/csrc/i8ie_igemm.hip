@@ -552,36 +552,78 @@ __device__ __forceinline__ uint32_t bmax4(uint32_t a, uint32_t b) {
   return re | (ro << 8);
 }
 
+// Byte-wise unsigned max without SWAR arithmetic: a dword's even and odd bytes are spread into two pairs of
+// 16-bit lanes (v_perm_b32, zero fill), the running maxima live in that form (v_pk_max_u16: two bytes per
+// instruction) and are packed back once per output (one more v_perm_b32).  The SWAR form (bmax4 above) cost
+// ~10 VALU operations per input dword and made this kernel VALU-bound (rocprofv3: 43 M VALU wave-instructions
+// per launch); this form needs 4.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+struct BytesEO {
+  us2 e, o;
+};
+__device__ __forceinline__ BytesEO spread_eo(uint32_t x) {
+  BytesEO r;
+  r.e = __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, x, 0x0c020c00u));  // [x0, 0, x2, 0]
+  r.o = __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, x, 0x0c030c01u));  // [x1, 0, x3, 0]
+  return r;
+}
+__device__ __forceinline__ void max_eo(BytesEO& m, uint32_t x) {
+  const BytesEO v = spread_eo(x);
+  m.e = __builtin_elementwise_max(m.e, v.e);
+  m.o = __builtin_elementwise_max(m.o, v.o);
+}
+__device__ __forceinline__ uint32_t pack_eo(const BytesEO& m) {
+  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, m.o), __builtin_bit_cast(uint32_t, m.e), 0x06020400u);
+}
+
+// KT: compile-time window size (0 = run-time k): the KT * KT window loads are issued together
+template <int KT>
 __global__ __launch_bounds__(256) void maxpool_u8_nhwc_kernel(const uint8_t* __restrict__ in,
-                                                              uint8_t* __restrict__ out, int64_t total, int inHp,
+                                                              uint8_t* __restrict__ out, uint32_t total, int inHp,
                                                               int inWp, int ib, int c16, int oh, int ow, int k, int s,
                                                               int outHp, int outWp, int ob, uint32_t lo4) {
   // XCD-aware partition (gridDim.x % 8 == 0): blocks with equal blockIdx % 8 share an L2, so each of the
   // eight groups sweeps one contiguous eighth of the output -- window rows shared by neighbouring output
-  // rows are then fetched into one L2 once (rocprofv3 FETCH_SIZE: 1.37x the input bytes without this)
-  const int64_t slab = ((total + 7) / 8 + 255) / 256 * 256;
-  const int64_t lo = (int64_t)(blockIdx.x & 7) * slab;
-  const int64_t hi = lo + slab < total ? lo + slab : total;
-  const int64_t gstride = (int64_t)(gridDim.x >> 3) * 256;
-  for (int64_t e = lo + (int64_t)(blockIdx.x >> 3) * 256 + threadIdx.x; e < hi; e += gstride) {
-    const int cc = (int)(e % c16);
-    int64_t t = e / c16;
-    const int x = (int)(t % ow);
-    t /= ow;
-    const int y = (int)(t % oh);
-    const int64_t img = t / oh;
+  // rows are then fetched into one L2 once (rocprofv3 FETCH_SIZE: 1.37x the input bytes without this,
+  // 1.07x with).  `total` (16-byte output chunks) < 2^31: the launcher splits larger batches, which keeps the
+  // index arithmetic in 32 bits (three 64-bit divisions per chunk were a third of the instruction count).
+  const uint32_t slab = ((total + 7) / 8 + 255) / 256 * 256;
+  const uint32_t lo = (blockIdx.x & 7) * slab;
+  const uint32_t hi = lo + slab < total ? lo + slab : total;
+  const uint32_t gstride = (gridDim.x >> 3) * 256u;
+  const BytesEO m0 = spread_eo(lo4);  // 0 (reference's running max start), or zp when relu is folded in
+  for (uint32_t e = lo + (blockIdx.x >> 3) * 256u + threadIdx.x; e < hi; e += gstride) {
+    const uint32_t t0 = e / (uint32_t)c16, cc = e - t0 * c16;
+    const uint32_t t1 = t0 / (uint32_t)ow, x = t0 - t1 * ow;
+    const uint32_t img = t1 / (uint32_t)oh, y = t1 - img * oh;
     const uint4* p = reinterpret_cast<const uint4*>(in) +
-                     ((img * inHp + (int64_t)y * s + ib) * inWp + (int64_t)x * s + ib) * c16 + cc;
-    uint4 m = make_uint4(lo4, lo4, lo4, lo4);  // 0 (reference's running max start), or zp when relu is folded in
-    for (int a = 0; a < k; ++a)
-      for (int b = 0; b < k; ++b) {
-        const uint4 v = p[((int64_t)a * inWp + b) * c16];
-        m.x = bmax4(m.x, v.x);
-        m.y = bmax4(m.y, v.y);
-        m.z = bmax4(m.z, v.z);
-        m.w = bmax4(m.w, v.w);
+                     (((size_t)img * inHp + (size_t)y * s + ib) * inWp + (size_t)x * s + ib) * c16 + cc;
+    BytesEO mx = m0, my = m0, mz = m0, mw = m0;
+    if constexpr (KT > 0) {
+      uint4 v[KT * KT];
+#pragma unroll
+      for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b) v[a * KT + b] = p[((size_t)a * inWp + b) * c16];
+#pragma unroll
+      for (int i = 0; i < KT * KT; ++i) {
+        max_eo(mx, v[i].x);
+        max_eo(my, v[i].y);
+        max_eo(mz, v[i].z);
+        max_eo(mw, v[i].w);
       }
-    reinterpret_cast<uint4*>(out)[((img * outHp + y + ob) * outWp + x + ob) * c16 + cc] = m;
+    } else {
+      for (int a = 0; a < k; ++a)
+        for (int b = 0; b < k; ++b) {
+          const uint4 v = p[((size_t)a * inWp + b) * c16];
+          max_eo(mx, v.x);
+          max_eo(my, v.y);
+          max_eo(mz, v.z);
+          max_eo(mw, v.w);
+        }
+    }
+    reinterpret_cast<uint4*>(out)[(((size_t)img * outHp + y + ob) * outWp + x + ob) * c16 + cc] =
+        make_uint4(pack_eo(mx), pack_eo(my), pack_eo(mz), pack_eo(mw));
   }
 }
 
@@ -1181,11 +1223,27 @@ int i8ie_launch_repack_smallc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, in
 int i8ie_launch_maxpool_nhwc(i8ie_ctx* ctx, const uint8_t* in, int ib, uint8_t* out, int ob, int n, int c, int h,
                              int w, int k, int s, int relu_zp) {
   const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
-  const int64_t total = (int64_t)n * oh * ow * (c / 16);
-  I8ieProfScope prof(ctx, "maxpool_u8_nhwc", 0.0, (double)n * c * h * w + 16.0 * total);
-  maxpool_u8_nhwc_kernel<<<(cap_grid(total, 256, 256 * 32) + 7) / 8 * 8, 256, 0, ctx->stream>>>(
-      in, out, total, h + 2 * ib, w + 2 * ib, ib, c / 16, oh, ow, k, s, oh + 2 * ob, ow + 2 * ob, ob,
-      (uint32_t)(relu_zp & 0xFF) * 0x01010101u);
-  I8IE_LAUNCH_CHECK();
+  const int c16 = c / 16;
+  const int64_t per_img = (int64_t)oh * ow * c16;
+  I8IE_REQUIRE(per_img > 0 && per_img < ((int64_t)1 << 31), "max-pool image too large");
+  // 32-bit chunk indices inside the kernel: batches beyond 2^31 - 1 chunks run as several launches
+  const int imgs_per = (int)((((int64_t)1 << 31) - 1) / per_img);
+  for (int i0 = 0; i0 < n; i0 += imgs_per) {
+    const int nb = n - i0 < imgs_per ? n - i0 : imgs_per;
+    const int64_t total = (int64_t)nb * per_img;
+    const uint8_t* src = in + (size_t)i0 * (h + 2 * ib) * (w + 2 * ib) * c;
+    uint8_t* dst = out + (size_t)i0 * (oh + 2 * ob) * (ow + 2 * ob) * c;
+    I8ieProfScope prof(ctx, "maxpool_u8_nhwc", 0.0, (double)nb * c * h * w + 16.0 * total);
+    const int grid = (cap_grid(total, 256, 256 * 32) + 7) / 8 * 8;
+    const uint32_t lo4 = (uint32_t)(relu_zp & 0xFF) * 0x01010101u;
+#define I8IE_POOL_LAUNCH(KT)                                                                                        \
+  maxpool_u8_nhwc_kernel<KT><<<grid, 256, 0, ctx->stream>>>(src, dst, (uint32_t)total, h + 2 * ib, w + 2 * ib, ib, \
+                                                            c16, oh, ow, k, s, oh + 2 * ob, ow + 2 * ob, ob, lo4)
+    if (k == 3) I8IE_POOL_LAUNCH(3);
+    else if (k == 2) I8IE_POOL_LAUNCH(2);
+    else I8IE_POOL_LAUNCH(0);
+#undef I8IE_POOL_LAUNCH
+    I8IE_LAUNCH_CHECK();
+  }
   return I8IE_OK;
 }
