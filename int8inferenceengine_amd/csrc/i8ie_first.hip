@@ -17,6 +17,7 @@
 //     wave-private LDS transpose, 16-byte NHWC stores.
 // INT32 accumulators are the reference's sums (K order permuted, padded taps have zero weights).
 #include <cstdlib>
+#include <type_traits>
 
 #include "i8ie_internal.h"
 
@@ -57,6 +58,16 @@ __device__ __forceinline__ uint32_t frequant_pack4(int c0, int c1, int c2, int c
 }
 
 constexpr int kMaxKS = 24;
+
+// compile-time loop: the body sees its index as a constant (a `#pragma unroll` loop left hipcc holding 26 more
+// VGPRs in the first-layer kernel: 190 against 164)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 
 struct FirstArgs {
   const uint8_t* img;  // grouped image [n][Hp][WG][16], bytes re-biased (^0x80)
@@ -238,19 +249,21 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
         // single accumulator chain an LDS round trip per step would otherwise be exposed
         constexpr int DEPTH = KS < 6 ? KS : 6;
         v4i ring[DEPTH];
-#pragma unroll
-        for (int j = 0; j < DEPTH; ++j) ring[j] = *reinterpret_cast<const v4i*>(abase + koff[j]);
+        static_for<0, DEPTH>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          ring[j] = *reinterpret_cast<const v4i*>(abase + koff[j]);
+        });
         __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks every read next to its MFMA (1 in flight)
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
+        static_for<0, KS>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
           const v4i af = ring[j % DEPTH];
-          if (j + DEPTH < KS) {
+          if constexpr (j + DEPTH < KS) {
             ring[j % DEPTH] = *reinterpret_cast<const v4i*>(abase + koff[j + DEPTH]);
             __builtin_amdgcn_sched_barrier(0);
           }
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(breg[j], af, acc, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-        }
+        });
         // epilogue: lane = pixel, regs = features (4 consecutive per group)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
