@@ -70,13 +70,18 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible (the INT8 path has no CPU fallback)")
+    # Rehearsal of the N > 1 control flow on a box with one GPU (RCCL refuses two ranks on one device): every
+    # rank uses device 0 and the collectives run over gloo on host copies.  Not a measurement.
+    rehearse = bool(os.environ.get("I8IE_BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
         # run our kernels on torch's current stream so the collective is stream-ordered behind them
         cx.use_stream(torch.cuda.current_stream().cuda_stream, local_rank)
     else:
@@ -100,8 +105,11 @@ def main():
     lab_loc = sharding.centred_argmax(fp32_net(i8ie.tensor(x_loc)).numpy(), centre)
     del fp32_net
     cx.trim()
+    def gather(t):  # [rows_local, C] on the GPU -> [n_total, C] on every rank
+        return sharding.gather_rows(t.cpu() if rehearse else t, n_total)
+
     if use_dist:
-        lab_all = sharding.gather_rows(torch.from_numpy(lab_loc.astype(np.float32)[:, None]).cuda(), n_total)
+        lab_all = gather(torch.from_numpy(lab_loc.astype(np.float32)[:, None]).cuda())
         lab_all = lab_all.cpu().numpy()[:, 0].astype(np.int64)
     else:
         lab_all = lab_loc
@@ -125,7 +133,7 @@ def main():
         if not use_dist:
             return y.numpy_async()
         cx.copy_to_ptr(y.data, stage.data_ptr())
-        full = sharding.gather_rows(stage, n_total)  # RCCL all-gather, stream-ordered behind the kernels
+        full = gather(stage)  # RCCL all-gather, stream-ordered behind the kernels
         if rank != 0:
             return None
         buf = host_logits[tick["i"] & 1]
@@ -232,7 +240,7 @@ def main():
                 "how": "FP32 batch in pinned host memory, async upload on the transfer stream overlapped with the previous batch's kernels"}
         del pin
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -341,6 +349,8 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "whole_step": whole,
         "kernel_ms_per_step": breakdown, "per_launch_shape": per_layer, "top1_vs_fp32_teacher": round(state["correct"] / n_total, 4),
         "prewarm_steps_untimed": prewarm,
+        **({"REHEARSAL": "all ranks on one GPU, gloo collectives on host copies: control flow only, not a measurement"}
+           if rehearse else {}),
         "step_discipline": ("depth-2 software pipeline: batch i+1 is launched before batch i's logits are awaited"
                             if pipelined else "synchronous: logits of batch i read before batch i+1 is launched"),
         ("ms_per_step_synchronous" if pipelined else "ms_per_step_pipelined"): round(other_ms, 4),
