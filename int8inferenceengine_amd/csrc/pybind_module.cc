@@ -327,9 +327,14 @@ struct Tensor {
   // include/tensor.h:106-133: at most one -1, no zeros, sizes must match
   Tensor<T> reshape(std::vector<ssize_t> shp) {
     realize();
-    // Views are defined on the reference's element order.  A border-free NHWC buffer is converted only when its
-    // bytes are observed (dptr() / numpy()): a Linear layer fed by the flattened view reads it as it lies.
-    if (st && !(st->layout == I8IE_LAYOUT_NHWC && st->border == 0)) st->to_nchw();
+    // Views are defined on the reference's element order, so the buffer goes back to NCHW here -- except for the
+    // flatten x.reshape(n, -1) of a border-free NHWC activation: that view is converted only if its bytes are
+    // observed (dptr() / numpy()); a Linear layer reads it as it lies (K walked in (h, w, c) order).  Any other
+    // new shape would disagree with the storage's logical dims for the layout-aware consumers.
+    const bool flatten = st && st->layout == I8IE_LAYOUT_NHWC && st->border == 0 && shp.size() == 2 &&
+                         (shp[0] == st->dn || (shp[0] < 0 && shp[1] == (ssize_t)st->dc * st->dh * st->dw) ||
+                          (shp[1] < 0 && shp[0] == st->dn));
+    if (st && !flatten) st->to_nchw();
     ssize_t midx = -1, sz = 1;
     for (size_t i = 0; i < shp.size(); ++i) {
       if (shp[i] < 0) {

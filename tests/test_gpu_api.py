@@ -169,3 +169,27 @@ def test_alexnet_batch_invariance(i8ie):
     part = net(i8ie.tensor(x[40:44])).numpy()
     assert np.array_equal(full[40:44].view(np.uint32), part.view(np.uint32))
     assert len(np.unique(full.argmax(1))) >= 1
+
+
+def test_views_of_nhwc_activations_keep_reference_element_order(i8ie):
+    """Conv outputs live NHWC internally.  reshape() views are defined on the reference's NCHW element order:
+    the flatten feeding a Linear layer stays lazy, every other view (and anything observing the bytes) must
+    see NCHW order."""
+    from int8inferenceengine_amd import workloads as wl
+
+    net = wl.calibrated("alexnet", wl.synthetic_state_dict("alexnet", seed=3))  # conv1: 96 features -> NHWC
+    x = wl.synthetic_input("alexnet", 2, seed=9)
+    conv = getattr(net, wl.layer_names("alexnet")[0])
+    q = i8ie.quantize(i8ie.tensor(x), 0.02, 120)
+    y = i8ie.relu(conv(q))                      # NHWC inside
+    assert i8ie.relu(conv(q)).data.layout() == 1
+    ref = y.numpy()                             # NCHW bytes, as the reference defines them
+    n, c, h, w = ref.shape
+    assert np.array_equal(y.reshape(n, -1).numpy(), ref.reshape(n, -1))           # flatten view
+    assert np.array_equal(y.reshape(n, c, h * w, 1).numpy(), ref.reshape(n, c, h * w, 1))  # 4-D -> 4-D view
+    assert np.array_equal(y.reshape(-1, c * h * w).numpy(), ref.reshape(-1, c * h * w))
+    y2 = i8ie.relu(conv(q))
+    v = y2.reshape(n, c, h * w, 1)              # view taken BEFORE anything observed the buffer
+    assert np.array_equal(i8ie.relu(v).numpy(), ref.reshape(n, c, h * w, 1))
+    assert np.array_equal(i8ie.max_pool2d(y2.reshape(n, c, h, w), 3, 2).numpy(),
+                          i8ie.max_pool2d(y, 3, 2).numpy())
