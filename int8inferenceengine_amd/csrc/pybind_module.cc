@@ -612,7 +612,6 @@ Tensor<u8_t> max_pool2d_u8(Tensor<u8_t>& in, ssize_t k, ssize_t s) {  // src/fun
                                   (int)ishp[3], kk, ss));
         }
         if (relu) check(i8ie_relu_u8(ctx(), (const uint8_t*)st->dev, (uint8_t*)st->dev, (int64_t)st->bytes, zp));
-        src = Tensor<u8_t>();
         return st;
       });
   return out;
@@ -818,7 +817,6 @@ class BaseLayer {
               auto st = nhwc_storage(oshp, border, zp_out);
               check(i8ie_layer_forward_f32_input(handle.get(), (const float*)src.qsrc->device_ptr(), m, h, w,
                                                  src.qscale, src.qzp, relu ? 1 : 0, (uint8_t*)st->dev, border));
-              src = Tensor<u8_t>();
               return st;
             }
           }
@@ -845,7 +843,8 @@ class BaseLayer {
           auto st = out_layout == I8IE_LAYOUT_NHWC ? nhwc_storage(oshp, ob, zp_out) : device_storage(obytes);
           check(i8ie_layer_forward_fused(handle.get(), ip, in_layout, in_border, m, h, w, s_in, zp_in, relu ? 1 : 0,
                                          (uint8_t*)st->dev, out_layout, ob, nullptr));
-          src = Tensor<u8_t>();  // release the input as soon as the launch is queued
+          // (the input is released when the last tensor holding this closure lets go of it: right after the
+          // launch in `x = relu(layer(x))`, later if the un-fused result is observed as well)
           return st;
         });
     if (!spatial && out.shape.size() == 2 && out.shape[1] <= 16) {
@@ -870,7 +869,6 @@ class BaseLayer {
             auto q = device_storage(obytes);  // u8 side output: only written when the fused kernel does not apply
             check(i8ie_layer_forward_dequant(handle.get(), ip, lay, m, hh, ww, s_in, zp_in, relu ? 1 : 0,
                                              (uint8_t*)q->dev, (float*)f->dev));
-            src2 = Tensor<u8_t>();
             return f;
           });
     }
