@@ -100,17 +100,20 @@ __device__ __forceinline__ uint32_t quant_exact(float x, float scale, float zpf,
   return (uint32_t)((int)t) & 0xFFu;
 }
 
+// IDX = uint32_t while the image has fewer than 2^31 groups (three 64-bit divisions per group were a large part
+// of this kernel's 53 M VALU wave-instructions per launch), int64_t beyond
+template <typename IDX>
 __global__ __launch_bounds__(256) void quantize_repack_kernel(const float* __restrict__ x, uint8_t* __restrict__ out,
                                                               int64_t total, int c, int h, int w, int Hp, int WG,
                                                               int pad, float scale, float zpf, float rscale,
                                                               uint32_t zp) {
-  const int64_t gstride = (int64_t)gridDim.x * 256;
+  const IDX gstride = (IDX)gridDim.x * 256;
   const size_t cs = (size_t)h * w;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += gstride) {
-    const int g = (int)(e % WG);
-    int64_t t = e / WG;
-    const int yp = (int)(t % Hp);
-    const int64_t img = t / Hp;
+  for (IDX e = (IDX)blockIdx.x * 256 + threadIdx.x; e < (IDX)total; e += gstride) {
+    const IDX t = e / (IDX)WG;
+    const int g = (int)(e - t * (IDX)WG);
+    const IDX img = t / (IDX)Hp;
+    const int yp = (int)(t - img * (IDX)Hp);
     const int y = yp - pad, x0 = 4 * g - pad;
     const bool yin = y >= 0 && y < h;
     const int yc = y < 0 ? 0 : (y >= h ? h - 1 : y);
@@ -348,9 +351,14 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
     I8ieProfScope prof(ctx, "quantize_repack_f32", 0.0, 4.0 * c.n * c.c * c.h * c.w + 16.0 * total);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    quantize_repack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.x, c.scratch, total, c.c, c.h, c.w, a.Hp, a.WG, c.pad,
-                                                                 c.q_scale, (float)c.q_zp, 1.0f / c.q_scale,
-                                                                 (uint32_t)(c.q_zp & 0xFF));
+    if (total < ((int64_t)1 << 31) - 256 * 4096)
+      quantize_repack_kernel<uint32_t><<<(int)blocks, 256, 0, ctx->stream>>>(
+          c.x, c.scratch, total, c.c, c.h, c.w, a.Hp, a.WG, c.pad, c.q_scale, (float)c.q_zp, 1.0f / c.q_scale,
+          (uint32_t)(c.q_zp & 0xFF));
+    else
+      quantize_repack_kernel<int64_t><<<(int)blocks, 256, 0, ctx->stream>>>(
+          c.x, c.scratch, total, c.c, c.h, c.w, a.Hp, a.WG, c.pad, c.q_scale, (float)c.q_zp, 1.0f / c.q_scale,
+          (uint32_t)(c.q_zp & 0xFF));
     I8IE_LAUNCH_CHECK();
     grouped = c.scratch;
   }
