@@ -145,7 +145,8 @@ struct Storage {
   void* dev = nullptr;
   i8ie_event* ready_ev = nullptr;  // recorded on the transfer stream behind the upload into `dev`
   bool upload_block = false;       // `dev` belongs to upload_cache()
-  py::object keep;                 // the pinned ndarray an asynchronous upload reads from
+  bool external = false;           // `dev` is foreign HIP memory (e.g. a torch tensor's): never freed here
+  py::object keep;                 // the pinned ndarray an asynchronous upload reads from / the foreign owner
   int bzp = -1;  // >= 0: bordered NHWC buffer with border bytes == bzp (returns to border_cache)
   std::vector<unsigned char> host;
   bool host_valid = false;
@@ -160,7 +161,7 @@ struct Storage {
     dn = (int)shp[0]; dc = (int)shp[1]; dh = (int)shp[2]; dw = (int)shp[3];
   }
   void to_nchw() {
-    if (layout == I8IE_LAYOUT_NCHW) return;
+    if (layout == I8IE_LAYOUT_NCHW || external) return;
     void* fresh = nullptr;
     const size_t logical = (size_t)dn * dc * dh * dw;
     check(i8ie_malloc(ctx(), logical, &fresh));
@@ -188,6 +189,7 @@ struct Storage {
     keep = py::object();  // the source may be refilled; the compute stream still has to wait on the event
   }
   ~Storage() {
+    if (external) return;  // the owner object in `keep` frees it
     if (!dev || !rt().ctx) return;
     if (ready_ev) {  // never consumed: let the copy finish before the block is reused
       i8ie_stream_wait_event(rt().ctx, ready_ev, 0);
@@ -481,6 +483,27 @@ Tensor<float> tensor_from_numpy(py::array_t<float, py::array::c_style | py::arra
   return t;
 }
 
+// Zero-copy view of foreign device memory (a torch tensor's data_ptr(), any hipMalloc block): the tensor reads it
+// in place; `owner` is kept alive as long as the tensor (or a reshape view of it) lives.  The memory must be
+// complete on this module's stream (share the stream with use_stream(), or synchronise the producer first).
+Tensor<float> tensor_from_device(uintptr_t ptr, std::vector<ssize_t> shape, py::object owner) {
+  if (ptr == 0 || (ptr & 3u) != 0) throw std::runtime_error("i8ie: tensor_from_device: null or misaligned pointer");
+  Tensor<float> t;
+  t.shape = std::move(shape);
+  t.size = 1;
+  for (ssize_t d : t.shape) {
+    if (d <= 0) throw std::runtime_error("i8ie: tensor_from_device: non-positive dimension");
+    t.size *= d;
+  }
+  (void)ctx();
+  t.st = std::make_shared<Storage>();
+  t.st->bytes = (size_t)t.size * sizeof(float);
+  t.st->dev = reinterpret_cast<void*>(ptr);
+  t.st->external = true;
+  t.st->keep = std::move(owner);
+  return t;
+}
+
 template <typename T>
 void bind_tensor(py::module_& m, const char* name) {
   using Fut = typename Tensor<T>::HostFuture;
@@ -510,6 +533,9 @@ void bind_tensor(py::module_& m, const char* name) {
       .def("reshape", [](Tensor<T>& t, std::vector<ssize_t> shape) { return t.reshape(std::move(shape)); })
       .def("layout", [](Tensor<T>& t) { t.realize(); return t.st ? t.st->layout : 0; })
       .def("prefetch", [](Tensor<T>& t) { (void)t.dptr(); })
+      // device address of the (launched, NCHW-ordered) contents: for __cuda_array_interface__ exports
+      .def("data_ptr", [](Tensor<T>& t) { return (uintptr_t)t.dptr(); })
+      .def("shape", [](const Tensor<T>& t) { return t.shape; })
       .def("nbytes", [](const Tensor<T>& t) { return (size_t)t.size * sizeof(T); });
 }
 
@@ -1060,6 +1086,7 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
   py::class_<Tensor<int32_t>>(m, "6TensorIiE").def("numpy", &Tensor<int32_t>::numpy);
 
   m.def("tensor", &tensor_from_numpy);  // src/pybind11.cc:38-40
+  m.def("tensor_from_device", &tensor_from_device);
   m.def("quantize", &quantize);         // src/pybind11.cc:41-45
   m.def("dequantize", &dequantize);     // src/pybind11.cc:46-48
   m.def("relu", &relu_f32);             // src/functional.cc:73-75

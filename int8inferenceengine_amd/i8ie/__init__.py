@@ -16,7 +16,7 @@ FullyConnected = Linear  # BASELINE.json's name for the same class (no such symb
 __all__ = [
     "tensor", "argmax", "relu", "max_pool2d", "quantize", "dequantize",
     "Linear", "FullyConnected", "Conv2d", "Tensor", "Module",
-    "synchronize", "set_device", "pinned_empty",
+    "synchronize", "set_device", "pinned_empty", "from_torch",
 ]
 
 
@@ -57,6 +57,19 @@ def pinned_empty(shape):
     the transfer stream, beside the kernels of the batch before; keep the contents unchanged until
     `Tensor.wait_upload()` returns."""
     return _C.pinned_empty([int(d) for d in shape])
+
+
+def from_torch(t, synchronize=True):
+    """Additive: wrap a contiguous float32 torch tensor on this GPU as a Tensor without copying (the reference's
+    `tensor()` copies an ndarray).  `synchronize` waits for torch's current stream first; pass False when the
+    engine was put on that stream with `_CXX_i8ie.use_stream`."""
+    import torch
+
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise TypeError("from_torch: need a contiguous float32 CUDA tensor")
+    if synchronize:
+        torch.cuda.current_stream(t.device).synchronize()
+    return Tensor(_C.tensor_from_device(t.data_ptr(), [int(d) for d in t.shape], t))
 
 
 def set_device(index):

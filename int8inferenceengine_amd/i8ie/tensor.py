@@ -47,6 +47,20 @@ class Tensor:
         self.data.prefetch()
         return self
 
+    @property
+    def __cuda_array_interface__(self):
+        """Additive: zero-copy export of a float32 / uint8 tensor (`torch.as_tensor(t, device="cuda")`, CuPy ...).
+        Launches pending work, puts the bytes in the reference's NCHW order and waits for the stream, so the
+        consumer may use any stream.  The tensor must outlive the consumer's view."""
+        name = type(self.data).__name__
+        typestr = {"6TensorIfE": "<f4", "6TensorIhE": "|u1", "6TensorIcE": "|i1", "6TensorIiE": "<i4"}.get(name)
+        if typestr is None:
+            raise TypeError("no array interface for %s" % name)
+        ptr = self.data.data_ptr()
+        _C.synchronize()
+        return {"shape": tuple(self.data.shape()), "typestr": typestr, "data": (ptr, False), "version": 2,
+                "strides": None}
+
     def numpy_async(self):
         """Additive: queue the device -> host copy behind this tensor's kernels and return a future
         (`.result()` -> ndarray, `.done()`), so the next batch can be launched before the wait."""

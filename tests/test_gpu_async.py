@@ -158,3 +158,32 @@ def test_pipelined_batches_equal_synchronous_batches(i8ie):
     got.append(pending.result())
     for w, g in zip(want, got):
         assert np.array_equal(w.view(np.uint32), g.view(np.uint32))
+
+
+def test_zero_copy_torch_interop(i8ie):
+    """a torch CUDA tensor enters the engine without a copy (`from_torch`), an engine
+    tensor leaves it without one (`__cuda_array_interface__`)."""
+    import orc
+    import torch
+
+    x = torch.empty((6, 3, 20, 20), dtype=torch.float32, device="cuda").uniform_(-2, 2)
+    t = i8ie.from_torch(x)
+    assert t.data.data_ptr() == x.data_ptr()                       # same memory
+    q = i8ie.quantize(t, 0.02, 99)
+    assert np.array_equal(q.numpy(), orc.quantize(x.cpu().numpy(), 0.02, 99))
+    v = t.reshape(6, -1)                                           # views keep the owner alive
+    del t, x
+    torch.cuda.empty_cache()
+    assert v.numpy().shape == (6, 1200)
+    # export: u8 and f32 results as torch tensors on the same memory
+    qt = torch.as_tensor(q, device="cuda")
+    assert qt.dtype == torch.uint8 and tuple(qt.shape) == (6, 3, 20, 20)
+    assert qt.data_ptr() == q.data.data_ptr()
+    assert np.array_equal(qt.cpu().numpy(), q.numpy())
+    d = i8ie.dequantize(q)
+    dt = torch.as_tensor(d, device="cuda")
+    assert dt.dtype == torch.float32 and np.array_equal(dt.cpu().numpy(), d.numpy())
+    with pytest.raises(TypeError):
+        i8ie.from_torch(torch.zeros(4, dtype=torch.float64, device="cuda"))
+    with pytest.raises(TypeError):
+        i8ie.from_torch(torch.zeros(4))
