@@ -1,0 +1,107 @@
+"""Seeded random differential sweep of the layer entry points against the oracle: random conv / linear
+geometries (all three conv paths, ragged channels, strides, paddings, kernel = image ...), random layouts,
+borders, fused ReLU and kernel variants.  Every case compares INT32 accumulators and u8 outputs bit-exactly.
+I8IE_FUZZ_CASES raises the case count for a long hunt (default: a quick sweep that fits the suite)."""
+import os
+
+import numpy as np
+import pytest
+
+import abi
+import synth
+
+pytestmark = pytest.mark.gpu
+N_CASES = int(os.environ.get("I8IE_FUZZ_CASES", "48"))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import int8inferenceengine_amd  # noqa: F401
+
+    g = abi.Ctx(0)
+    yield g
+    g.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    import orc as o
+
+    return o
+
+
+def _conv_geom(rng):
+    kind = rng.integers(0, 4)
+    if kind == 0:    # path A candidates: channels % 16 == 0
+        c = int(rng.choice([16, 32, 48, 64, 96, 128]))
+    elif kind == 1:  # small-C path candidates (stride % 4 == 0 chosen below)
+        c = int(rng.integers(1, 5))
+    else:            # anything
+        c = int(rng.integers(1, 40))
+    k = int(rng.choice([1, 2, 3, 5, 7, 11]))
+    stride = int(rng.choice([4, 8])) if kind == 1 else int(rng.integers(1, 4))
+    pad = int(rng.integers(0, k // 2 + 2))
+    h = int(rng.integers(max(k - 2 * pad, 1), 30))
+    w = int(rng.integers(max(k - 2 * pad, 1), 30))
+    h, w = max(h, k - 2 * pad), max(w, k - 2 * pad)
+    kc = int(rng.choice([1, 7, 16, 20, 32, 33, 64, 96, 130, 200]))
+    n = int(rng.integers(1, 6))
+    return n, c, h, w, kc, k, stride, pad
+
+
+@pytest.mark.parametrize("case", range(N_CASES))
+def test_random_conv_against_oracle(gpu, orc, case):
+    rng = np.random.default_rng(10_000 + case)
+    n, c, h, w, kc, k, stride, pad = _conv_geom(rng)
+    zp_in = int(rng.integers(0, 256))
+    cs = synth.conv_case(orc, 20_000 + case, n, c, h, w, kc, k, stride, pad, s_in=float(rng.uniform(0.005, 0.05)),
+                         zp_in=zp_in)
+    in_nhwc = bool(rng.integers(0, 2))
+    out_nhwc = bool(rng.integers(0, 2))
+    ib = int(rng.choice([0, pad, pad + 1])) if in_nhwc else 0
+    ob = int(rng.integers(0, 3)) if (out_nhwc and kc % 16 == 0) else 0
+    relu = bool(rng.integers(0, 2))
+    variant = int(rng.choice([0, 0, 3, 5]))
+    fallback = bool(rng.integers(0, 6) == 0)
+    lib = abi.lib()
+    abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, variant))
+    gpu.set_force_fallback(fallback)
+    try:
+        out, acc, _ = gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
+                                              cs["s_out"], cs["zp_out"], stride=stride, pad=pad, in_nhwc=in_nhwc,
+                                              out_nhwc=out_nhwc, relu=relu, in_border=ib, out_border=ob)
+    finally:
+        gpu.set_force_fallback(False)
+        abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
+    want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
+    ctx = "geom %s nhwc %s/%s borders %d/%d relu %s variant %d fallback %s" % (
+        (n, c, h, w, kc, k, stride, pad), in_nhwc, out_nhwc, ib, ob, relu, variant, fallback)
+    assert np.array_equal(acc, cs["acc"]), ctx
+    assert np.array_equal(out, want), ctx
+
+
+@pytest.mark.parametrize("case", range(max(N_CASES // 2, 8)))
+def test_random_linear_against_oracle(gpu, orc, case):
+    rng = np.random.default_rng(30_000 + case)
+    m = int(rng.choice([1, 3, 31, 64, 125, 130, 257]))
+    k = int(rng.choice([1, 7, 16, 64, 100, 784, 800, 1024, 4096]))
+    n = int(rng.choice([1, 3, 10, 16, 17, 40, 100, 256, 500]))
+    cs = synth.linear_case(orc, 40_000 + case, m, k, n, s_in=float(rng.uniform(0.005, 0.05)),
+                           zp_in=int(rng.integers(0, 256)))
+    relu = bool(rng.integers(0, 2))
+    fallback = bool(rng.integers(0, 6) == 0)
+    flat = None
+    if k % 4 == 0 and rng.integers(0, 2):
+        hw = int(rng.choice([d for d in (4, 2) if k % d == 0]))
+        flat = (k // hw, hw // 2 if hw == 4 else 1, 2)  # (c, h, w) with h * w == hw
+    gpu.set_force_fallback(fallback)
+    try:
+        out, acc, _ = gpu.layer_forward_fused("linear", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"],
+                                              cs["s_w"], cs["s_out"], cs["zp_out"], relu=relu,
+                                              in_nhwc=flat is not None, flat_chw=flat)
+    finally:
+        gpu.set_force_fallback(False)
+    want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
+    ctx = "m %d k %d n %d relu %s fallback %s flat %s" % (m, k, n, relu, fallback, flat)
+    assert np.array_equal(acc, cs["acc"]), ctx
+    assert np.array_equal(out, want), ctx
