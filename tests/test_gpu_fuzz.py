@@ -105,3 +105,70 @@ def test_random_linear_against_oracle(gpu, orc, case):
     ctx = "m %d k %d n %d relu %s fallback %s flat %s" % (m, k, n, relu, fallback, flat)
     assert np.array_equal(acc, cs["acc"]), ctx
     assert np.array_equal(out, want), ctx
+
+
+# ---- random small networks through the i8ie surface (deferred launches, layouts, borders, flatten, fused head)
+def _random_network(rng):
+    c = int(rng.choice([1, 3, 4, 16]))
+    h = int(rng.integers(14, 34))
+    w = int(rng.integers(14, 34))
+    layers, spec = {}, []
+    ch, hh, ww = c, h, w
+    for i in range(int(rng.integers(1, 4))):
+        k = int(rng.choice([1, 3, 5]))
+        stride = int(rng.choice([1, 1, 2, 4]))
+        pad = int(rng.integers(0, k // 2 + 1))
+        oh, ow = (hh - k + 2 * pad) // stride + 1, (ww - k + 2 * pad) // stride + 1
+        if oh < 3 or ow < 3:
+            break
+        oc = int(rng.choice([8, 16, 20, 32, 48, 64]))
+        layers["conv%d" % i] = ("conv", ch, oc, k, stride, pad)
+        spec.append(("layer", "conv%d" % i))
+        ch, hh, ww = oc, oh, ow
+        if rng.integers(0, 4):
+            spec.append(("relu",))
+        if rng.integers(0, 2):
+            pk, ps = (2, 2) if rng.integers(0, 2) else (3, 2)
+            if hh >= pk + 1 and ww >= pk + 1:
+                spec.append(("pool", pk, ps))
+                hh, ww = (hh - pk) // ps + 1, (ww - pk) // ps + 1
+                if rng.integers(0, 3) == 0:
+                    spec.append(("relu",))
+    feat = ch * hh * ww
+    spec.append(("flatten", feat))
+    dims = [feat] + [int(rng.choice([16, 50, 64, 100])) for _ in range(int(rng.integers(0, 3)))]
+    dims.append(int(rng.choice([1, 10, 16, 17])))
+    for j in range(len(dims) - 1):
+        layers["fc%d" % j] = ("fc", dims[j], dims[j + 1])
+        spec.append(("layer", "fc%d" % j))
+        if j < len(dims) - 2 and rng.integers(0, 3):
+            spec.append(("relu",))
+    return layers, spec, (c, h, w)
+
+
+@pytest.mark.parametrize("case", range(max(N_CASES // 4, 12)))
+def test_random_network_logits_against_oracle(orc, case):
+    import int8inferenceengine_amd  # noqa: F401
+    import i8ie
+    import pipeline
+    from int8inferenceengine_amd import workloads as wl
+
+    rng = np.random.default_rng(50_000 + case)
+    entry = _random_network(rng)
+    name = "_fuzz_%d" % case
+    wl.NETWORKS[name] = entry
+    try:
+        sd = wl.synthetic_state_dict(name, seed=60_000 + case)
+        net = wl.calibrated(name, sd, calib_batch=wl.synthetic_input(name, 24, seed=case))
+        batch = int(rng.choice([1, 5, 32]))
+        x = wl.synthetic_input(name, batch, seed=70_000 + case)
+        got = net(i8ie.tensor(x)).numpy()
+        qlayers = pipeline.quantize_layers(entry, sd)
+        qparams = {a: getattr(net, a).output_qparams() for a in wl.layer_names(name)}
+        want = pipeline.forward(entry, x, qlayers, qparams)
+        assert got.shape == want.shape, (entry, got.shape, want.shape)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), entry
+        # a second forward reuses cached buffers / borders: same answer
+        assert np.array_equal(net(i8ie.tensor(x)).numpy().view(np.uint32), want.view(np.uint32)), entry
+    finally:
+        del wl.NETWORKS[name]
