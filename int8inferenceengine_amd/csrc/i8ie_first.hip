@@ -325,6 +325,8 @@ struct I8ieFirstCall {
 };
 
 int i8ie_first_supported(int c, int stride, int n_out, int K2, int KH, int KWG, int OW) {
+  static const bool off = std::getenv("I8IE_NO_SMALLC") != nullptr;  // A/B aid: route path B through the generic kernel
+  if (off) return 0;
   if (c > 3 || stride % 4 != 0) return 0;  // 3 data channels + 1 pad byte per pixel
   if (n_out % 32 != 0 || n_out / 32 > 8) return 0;
   if ((K2 + 31) / 32 > kMaxKS) return 0;
