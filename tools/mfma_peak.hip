@@ -421,6 +421,59 @@ void run4(int blocks_per_cu, int iters) {
   hipFree(out);
 }
 
+// same question for the other int8 MFMA shape: 16x16x64 (4 accumulator registers, 16 passes of work per 4)
+template <bool RANDOM>
+__global__ __launch_bounds__(256) void k5(int iters, int* out) {
+  const int tid = threadIdx.x + blockIdx.x * 256;
+  v4i acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = v4i{0, 0, 0, 0};
+  v4i ap[8], bp[8];
+  unsigned h = tid * 2654435761u + 12345u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      h = h * 1664525u + 1013904223u;
+      ap[i][q] = RANDOM ? (int)h : 0x01010101;
+      h = h * 1664525u + 1013904223u;
+      bp[i][q] = RANDOM ? (int)h : 0x01010101;
+    }
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        acc[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bp[(u + j) & 7], ap[(u + 3 * j) & 7], acc[j], 0, 0, 0);
+    }
+  }
+  int s = 0;
+  for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+  out[tid] = s;
+}
+
+template <bool RANDOM>
+void run5(int blocks_per_cu, int iters) {
+  int* out;
+  const int blocks = 256 * blocks_per_cu;
+  hipMalloc(&out, blocks * 256 * 4);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  k5<RANDOM><<<blocks, 256>>>(iters / 10, out);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  k5<RANDOM><<<blocks, 256>>>(iters, out);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double ops = (double)blocks * 4 * iters * 64 * (2.0 * 16 * 16 * 64);
+  printf("register-only MFMA 16x16x64, %s operands, %d blocks/CU, %.1f ms run: %.0f TOPS\n", RANDOM ? "random" : "constant", blocks_per_cu, ms,
+         ops / (ms * 1e-3) / 1e12);
+  hipFree(out);
+}
+
 template <int MODE>
 void run(const char* name, int blocks_per_cu) {
   int* out;
@@ -452,6 +505,8 @@ int main() {
   run4<false>(2, 40000);
   run4<true>(2, 40000);
   run4<true>(1, 40000);
+  run5<false>(2, 20000);
+  run5<true>(2, 20000);
 
   for (int b = 1; b <= 2; ++b) {
     run<0>("mfma only", b);
