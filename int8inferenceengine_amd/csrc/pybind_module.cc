@@ -1180,6 +1180,14 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
     check(i8ie_ctx_create_on_stream(device, (void*)stream, &rt().ctx));
   });
   m.def("set_calibration_seed", [](long seed) { rt().calib_seed = seed; });
+  // the layers' calibrator on its own (host code, no GPU): feed chunks through sample(), then get_range()
+  m.def("calibrator_range",
+        [](std::vector<py::array_t<float, py::array::c_style | py::array::forcecast>> chunks, float quantile) {
+          Calibrator cal;
+          for (auto& c : chunks) cal.sample(c.data(), c.size());
+          auto [scale, zp] = cal.get_range(quantile);
+          return py::make_tuple(scale, (int)zp);
+        });
   // raw device copy into / out of foreign HIP memory (e.g. a torch tensor's data_ptr) for the
   // multi-GPU logits gather; both sides must be used on this module's stream or synchronised.
   m.def("copy_to_ptr", [](Tensor<float>& t, uintptr_t dst) {

@@ -13,15 +13,15 @@
  *
  * PINNING STATUS
  *   pinned against the reference's own compiled code (oracle/_ref, built from
- *   src/quantize_utils.cc + src/functional.cc where they lie):
+ *   src/quantize_utils.cc + src/functional.cc + src/calibrator.cc where they lie):
  *     orc_quantize_f32_u8, orc_dequantize_u8_f32, orc_down_scale,
- *     orc_relu_u8, orc_max_pool2d_u8          (tests/golden/ref_*.npz)
+ *     orc_relu_u8, orc_max_pool2d_u8, orc_calib_range   (tests/golden/ref_*.npz)
  *   PARITY UNPINNED by a reference run (src/conv2d.cc, src/fully_connected.cc
  *   and src/layer.cc include mkl.h, which this image lacks, so those
  *   translation units are unbuildable here; the reference's own tests hold no
  *   golden vectors for them):
  *     orc_quantize_weight, orc_conv_offsets, orc_linear_offsets, orc_im2col_u8,
- *     orc_gemm_u8s8s32, orc_conv2d_u8, orc_linear_u8, orc_calib_range
+ *     orc_gemm_u8s8s32, orc_conv2d_u8, orc_linear_u8
  *   For these the integer contraction is exact by definition
  *   (C = sum A*B + oc) and is cross-checked in tests/ against an independent
  *   int64 numpy/torch formulation; the float epilogue they feed is the pinned

@@ -2,6 +2,7 @@
 // of the reference that compile from their own sources in this image:
 //     /root/reference/src/quantize_utils.cc   (quantize / dequantize / down_scale)
 //     /root/reference/src/functional.cc       (relu<u8>, max_pool2d<u8>)
+//     /root/reference/src/calibrator.cc       (Calibrator::sample / get_range)
 // They are compiled WHERE THEY LIE by oracle/Makefile (target `ref`) into
 // oracle/_ref/ (git-ignored).  Nothing from the reference is copied into this
 // repository.  The rest of the reference (conv2d.cc, fully_connected.cc,
@@ -12,11 +13,14 @@
 // container) to produce golden vectors, and by tests/ to validate
 // oracle/i8ie_oracle.c.  /root/reference does not exist on the GPU box.
 #include <cstring>
+#include <memory>
+#include <stdexcept>
 #include <vector>
 
 #include "pybind11/numpy.h"
 #include "pybind11/pybind11.h"
 #include "pybind11/stl.h"
+#include "calibrator.h"      // reference header (include/calibrator.h)
 #include "quantize_utils.h"  // reference header (include/quantize_utils.h)
 #include "tensor.h"          // reference header (include/tensor.h)
 
@@ -85,6 +89,20 @@ PYBIND11_MODULE(_i8ie_ref_partial, m) {
                      sb, sc, (u8_t)zp_c);
           return out;
         });
+  // reference src/calibrator.cc:6-40.  sample() is deterministic while the reservoir is filling (the first
+  // num_samples = 1000 values are appended in order; only later values draw from std::random_device), and
+  // get_range() always is -- but it sorts all 1000 slots, so it is only meaningful once exactly 1000 values
+  // were appended.  `chunks` are fed through sample() one after the other and must total 1000 values.
+  m.def("calib_range", [](std::vector<py::array_t<float, py::array::c_style | py::array::forcecast>> chunks,
+                          float quantile) {
+    ssize_t total = 0;
+    for (auto& c : chunks) total += c.size();
+    if (total != num_samples) throw std::runtime_error("calib_range: feed exactly num_samples values");
+    auto cal = std::make_unique<Calibrator>();
+    for (auto& c : chunks) cal->sample(const_cast<float*>(c.data()), c.size());
+    auto [scale, zp] = cal->get_range(quantile);
+    return py::make_tuple(scale, (int)zp);
+  });
   // reference src/functional.cc:66-82: relu(T), max_pool2d(T, kernel_size, strides)
   declare_tensor_funcs(m);
 }

@@ -9,8 +9,9 @@ only, no pickles) next to this file.  The fixtures are committed; the reference
 itself never travels.
 
 Covers SURVEY.md section 8 rows a1 (quantize), a5 (down_scale), a6 (dequantize),
-a7 (relu u8), a8 (max_pool2d u8).  Rows a2/a3/a4/a10 live in translation units
-that include mkl.h (absent from the image) and cannot be built here.
+a7 (relu u8), a8 (max_pool2d u8) and the calibrator's range computation
+(src/calibrator.cc, compiled the same way).  Rows a2/a3/a4/a10 live in translation
+units that include mkl.h (absent from the image) and cannot be built here.
 
 usage:  python tests/golden/make_golden.py
 """
@@ -27,7 +28,12 @@ import _i8ie_ref_partial as ref  # noqa: E402
 rng = np.random.default_rng(20261004)
 
 
+ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]  # e.g. --only=ref_calib_range.npz
+
+
 def save(name, cases):
+    if ONLY and name not in ONLY:
+        return  # keep the committed fixture byte for byte
     flat = {}
     for i, case in enumerate(cases):
         for k, v in case.items():
@@ -120,3 +126,34 @@ for k, s, shape in [(3, 2, (2, 5, 55, 55)), (3, 2, (3, 4, 27, 27)), (3, 2, (2, 6
     assert out.zero_point() == 77
     p_cases.append(dict(q=q, par=np.array([k, s], np.float64), out=out.numpy().copy()))
 save("ref_maxpool.npz", p_cases)
+
+
+# ---- calibrator: Calibrator::sample (deterministic while the 1000-slot reservoir fills) + get_range -------
+# src/calibrator.cc:6-40.  1000 values, fed in one or several sample() calls, then get_range(quantile).
+crng = np.random.default_rng(777)
+c_cases = []
+
+
+def add_c(values, quantile, cuts=()):
+    v = np.ascontiguousarray(values, np.float32)
+    assert v.size == 1000
+    chunks = np.split(v, list(cuts)) if cuts else [v]
+    scale, zp = ref.calib_range([np.ascontiguousarray(c) for c in chunks], quantile)
+    c_cases.append(dict(x=v, par=np.array([quantile] + list(cuts), np.float64), scale=np.float32(scale),
+                        zp=np.int32(zp)))
+
+
+for qt in (1.0, 0.999, 0.99, 0.9):
+    add_c(crng.normal(0.3, 2.0, 1000), qt)
+    add_c(crng.uniform(-4, 1, 1000), qt, cuts=(400,))
+add_c(crng.uniform(0.5, 9, 1000), 1.0)                    # all positive: zero point 0, scale = max / 255
+add_c(crng.uniform(0.5, 9, 1000), 0.99, cuts=(1, 999))
+add_c(-crng.uniform(0.5, 9, 1000), 1.0)                   # all negative: zero point 254 / 255
+add_c(-crng.uniform(0.5, 9, 1000), 0.95)
+add_c(np.zeros(1000), 1.0)                                # nothing but zeros: scale falls back to 1
+add_c(np.concatenate([np.zeros(999), [1e-30]]), 1.0)
+add_c(np.concatenate([crng.normal(0, 1, 999), [1e6]]), 1.0)   # one outlier stretches the range ...
+add_c(np.concatenate([crng.normal(0, 1, 999), [1e6]]), 0.999)  # ... a quantile drops it
+add_c(crng.normal(0, 1e-4, 1000), 0.999)
+add_c(np.linspace(-1, 1, 1000), 0.5)
+save("ref_calib_range.npz", c_cases)

@@ -147,3 +147,28 @@ def test_calib_range_restatement(orc):
     zp_ref = int(255 * (0 - float(mn)) / (float(mx) - float(mn) + 1e-9))
     assert zp == zp_ref
     assert scale == np.float32((0 - mn) / np.float32(zp)) if zp else np.float32((mx - mn) / 255)
+
+
+def test_calib_range_golden(orc):
+    """Calibrator::sample + get_range of the reference's own compiled src/calibrator.cc (tests/golden/
+    make_golden.py): 18 cases -- quantiles, values fed in several sample() calls, one-sided ranges (zero point
+    0 / 255), the all-zero fallback scale 1, an outlier with and without a quantile that drops it."""
+    n = 0
+    for case in load_cases("ref_calib_range.npz"):
+        q = float(case["par"][0])
+        scale, zp = orc.calib_range(case["x"].copy(), 1000, q)
+        assert np.float32(scale).view(np.uint32) == case["scale"].view(np.uint32) and int(zp) == int(case["zp"])
+        n += 1
+    assert n == 18
+
+
+def test_product_calibrator_golden():
+    """The same vectors through the calibrator inside _CXX_i8ie (host code of the layers' prepare/convert)."""
+    import int8inferenceengine_amd  # noqa: F401
+    import _CXX_i8ie as cx
+
+    for case in load_cases("ref_calib_range.npz"):
+        q, cuts = float(case["par"][0]), [int(c) for c in case["par"][1:]]
+        chunks = np.split(case["x"], cuts) if cuts else [case["x"]]
+        scale, zp = cx.calibrator_range([np.ascontiguousarray(c) for c in chunks], q)
+        assert np.float32(scale).view(np.uint32) == case["scale"].view(np.uint32) and int(zp) == int(case["zp"])
