@@ -295,6 +295,9 @@ def main():
         # context, not the contract's peak: what register-only int8 MFMA sustains on this chip when the operands
         # toggle (tools/mfma_peak.hip k4; constant operands reach 4400-4900): profiles/r01h_mfma_peak_and_power.txt
         "sustained_mfma_only_tops": {"random_operands": 3400.0, "constant_operands": 4860.0},
+        # rocm-smi while this kernel runs (profiles/r01j_clock_probe.txt): power-capped on toggling operands
+        "sclk_mhz_under_this_kernel": {"random_operands": 1912, "constant_operands": 2400, "nominal": 2400},
+        "package_power_w_under_this_kernel": {"random_operands": 1370, "constant_operands": 1192},
         "frac_of_sustained_random_operand_rate": round(achieved / 3400.0, 4),
     }
     total_dev_ms = sum(v["ms"] for v in kernels.values())
