@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline sample")
     ap.add_argument("--force-dist", action="store_true", help="take the torch.distributed path even with one rank")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: --batch images PER GPU (global batch = batch x GPUs); default is the strong "
+                         "scaling BASELINE.json configs[4] names (global batch fixed, sharded)")
     ap.add_argument("--sync-steps", action="store_true",
                     help="read every batch's logits before launching the next batch (no software pipeline)")
     return ap.parse_args()
@@ -88,7 +91,7 @@ def main():
         cx.set_device(local_rank)
 
     name = args.network
-    n_total = args.batch
+    n_total = args.batch * world if args.weak else args.batch
     start, stop = sharding.shard_bounds(n_total, rank, world)
 
     # ---- model: the reference workflow, prepare -> one FP32 batch -> convert (identical on every rank)
@@ -350,7 +353,7 @@ def main():
     out = {
         "metric": "images/sec AlexNet-INT8 224x224 bs=1000", "value": round(value, 1), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
         "config": {"workload": "%s INT8 forward + top-1, %dx%dx%d input, global batch %d sharded over %d GPU(s)"
                    % ((name,) + wl.NETWORKS[name][2] + (n_total, world)),
                    "global_batch": n_total, "per_gpu_batch": stop - start, "parallelism": "batch-shard x%d + logits all-gather" % world},
