@@ -16,12 +16,16 @@
  *   src/quantize_utils.cc + src/functional.cc + src/calibrator.cc where they lie):
  *     orc_quantize_f32_u8, orc_dequantize_u8_f32, orc_down_scale,
  *     orc_relu_u8, orc_max_pool2d_u8, orc_calib_range   (tests/golden/ref_*.npz)
+ *   pinned against the reference's GEMM provider (Intel MKL cblas_gemm_s8u8s32, the call at
+ *   src/conv2d.cc:131-133 / src/fully_connected.cc:39-41; MKL 2021.4 shared objects are in this image and
+ *   are called directly through ctypes by tests/golden/make_golden_mkl.py -- nothing of the reference is
+ *   built for this): orc_gemm_u8s8s32                   (tests/golden/mkl_gemm_s8u8s32.npz)
  *   PARITY UNPINNED by a reference run (src/conv2d.cc, src/fully_connected.cc
  *   and src/layer.cc include mkl.h, which this image lacks, so those
  *   translation units are unbuildable here; the reference's own tests hold no
  *   golden vectors for them):
  *     orc_quantize_weight, orc_conv_offsets, orc_linear_offsets, orc_im2col_u8,
- *     orc_gemm_u8s8s32, orc_conv2d_u8, orc_linear_u8
+ *     and the composition of the pinned pieces in orc_conv2d_u8 / orc_linear_u8
  *   For these the integer contraction is exact by definition
  *   (C = sum A*B + oc) and is cross-checked in tests/ against an independent
  *   int64 numpy/torch formulation; the float epilogue they feed is the pinned

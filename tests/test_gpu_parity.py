@@ -473,3 +473,22 @@ def test_forward_dequant_general_linear_needs_u8_buffer(gpu, orc):
     lib.i8ie_layer_destroy(L)
     for d in (di, o8, of):
         d.free()
+
+
+def test_gpu_contraction_against_the_reference_gemm_provider(gpu):
+    """tests/golden/mkl_gemm_s8u8s32.npz holds results of MKL's cblas_gemm_s8u8s32 -- the routine the reference
+    calls -- on seeded operands.  With zp_in = 0 the layer's own offset vector is zero, so the product's INT32
+    accumulators for (A, B) must equal MKL's C minus the fixture's oc, bit for bit (MFMA contraction, split-K,
+    the classifier-head dot4 kernel and the padded-K fallback all get exercised by the case shapes)."""
+    n = 0
+    for c in load_cases("mkl_gemm_s8u8s32.npz"):
+        A, B, oc, Cm = c["A"], c["B"], c["oc"], c["C"]
+        qb = np.zeros(B.shape[0], np.int8)
+        _, acc, got_oc = gpu.linear(A, B, qb, np.float32(1.0), 0, np.float32(1.0), np.float32(1.0), 0)
+        assert not got_oc.any()
+        assert np.array_equal(acc, Cm - oc[None, :])
+        out2, acc2, _ = gpu.layer_forward_fused("linear", A, B, qb, np.float32(1.0), 0, np.float32(1.0),
+                                                np.float32(1.0), 0)
+        assert np.array_equal(acc2, Cm - oc[None, :])
+        n += 1
+    assert n == 10

@@ -172,3 +172,41 @@ def test_product_calibrator_golden():
         chunks = np.split(case["x"], cuts) if cuts else [case["x"]]
         scale, zp = cx.calibrator_range([np.ascontiguousarray(c) for c in chunks], q)
         assert np.float32(scale).view(np.uint32) == case["scale"].view(np.uint32) and int(zp) == int(case["zp"])
+
+
+def test_contraction_against_the_reference_gemm_provider(orc):
+    """The reference's contraction is Intel MKL's cblas_gemm_s8u8s32 (src/conv2d.cc:131-133,
+    src/fully_connected.cc:39-41).  tests/golden/make_golden_mkl.py called that entry point with the
+    reference's argument pattern (row-major, A u8 not transposed, B s8 transposed, CblasRowOffset: oc[j] added
+    to column j, alpha 1, beta 0, zero operand offsets) on seeded operands incl. the extreme 255 x (127 | -128)
+    case; the oracle's GEMM must reproduce MKL's INT32 results exactly."""
+    n = 0
+    for c in load_cases("mkl_gemm_s8u8s32.npz"):
+        got = orc.gemm_u8s8s32(c["A"], c["B"], c["oc"])
+        assert np.array_equal(got, c["C"])
+        n += 1
+    assert n == 10
+
+
+def test_contraction_against_live_mkl_when_present(orc):
+    """Same check against MKL itself where its runtime is installed (this image: /opt/conda/lib).  Skipped when
+    absent, and on non-Intel hosts, where MKL may take a vpmaddubsw path that saturates in int16."""
+    import ctypes as C
+    import os
+
+    path = os.environ.get("I8IE_MKL_RT", "/opt/conda/lib/libmkl_rt.so.1")
+    if not os.path.exists(path) or "GenuineIntel" not in open("/proc/cpuinfo").read():
+        pytest.skip("no MKL runtime / not an Intel host")
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
+    mkl = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    rng = np.random.default_rng(9)
+    for M, K, N in ((17, 363, 20), (40, 4096, 10), (3, 800, 500)):
+        A = rng.integers(0, 256, (M, K), dtype=np.uint8)
+        B = rng.integers(-128, 128, (N, K), dtype=np.int8)
+        oc = rng.integers(-50000, 50000, N).astype(np.int32)
+        Cm = np.empty((M, N), np.int32)
+        mkl.cblas_gemm_s8u8s32(101, 111, 112, 171, C.c_int(M), C.c_int(N), C.c_int(K), C.c_float(1.0),
+                               A.ctypes.data_as(C.c_void_p), C.c_int(K), C.c_int8(0), B.ctypes.data_as(C.c_void_p),
+                               C.c_int(K), C.c_int8(0), C.c_float(0.0), Cm.ctypes.data_as(C.c_void_p), C.c_int(N),
+                               oc.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(orc.gemm_u8s8s32(A, B, oc), Cm)
