@@ -207,6 +207,27 @@ void orc_gemm_u8s8s32(int M, int N, int K, const uint8_t* A, const int8_t* B,
   gemm_rows(M, N, K, A, B, oc, C);
 }
 
+/* Optional GEMM provider for the TIMED CPU BASELINE: the address of the reference's own provider entry point,
+ * Intel MKL's cblas_gemm_s8u8s32, when its runtime is installed on the host (oracle/orc.py loads it with
+ * ctypes; nothing of the reference is built).  With a provider set, orc_conv2d_u8 / orc_linear_u8 call it
+ * exactly where and how the reference does (src/conv2d.cc:131-133 inside the OpenMP loop over images,
+ * src/fully_connected.cc:39-41 as one call that MKL threads itself); results must equal gemm_rows (the
+ * caller verifies that on the host before trusting a time).                                              */
+typedef void (*orc_gemm_provider_fn)(int layout, int transa, int transb, int offsetc, int m, int n, int k,
+                                     float alpha, const void* a, int lda, int8_t ao, const void* b, int ldb,
+                                     int8_t bo, float beta, int32_t* c, int ldc, const int32_t* co);
+static orc_gemm_provider_fn g_gemm_provider = 0;
+void orc_set_gemm_provider(void* fn) { g_gemm_provider = (orc_gemm_provider_fn)fn; }
+static void provider_gemm(int M, int N, int K, const uint8_t* A, const int8_t* B, const int32_t* oc, int32_t* C) {
+  /* CblasRowMajor, CblasNoTrans, CblasTrans, CblasRowOffset */
+  g_gemm_provider(101, 111, 112, 171, M, N, K, 1.0f, A, K, 0, B, K, 0, 0.0f, C, N, oc);
+}
+void orc_gemm_u8s8s32_provider(int M, int N, int K, const uint8_t* A, const int8_t* B,
+                               const int32_t* oc, int32_t* C) {
+  if (g_gemm_provider) provider_gemm(M, N, K, A, B, oc, C);
+  else gemm_rows(M, N, K, A, B, oc, C);
+}
+
 /* ------------------------------------------------------------------ a2 --
  * src/conv2d.cc:100-142  Conv2d::forward_prop(Tensor<u8>&&)
  *   oc (a4) once; then per image (OpenMP over the batch, :125):
@@ -229,7 +250,8 @@ void orc_conv2d_u8(const uint8_t* in, int n, int c, int h, int w,
     uint8_t* hwc = (uint8_t*)malloc((size_t)M * N);
     orc_im2col_u8(mat, in + (int64_t)i * c * h * w, c, h, w, kh, kw, stride,
                   pad, zp_in);
-    gemm_rows(M, N, K, mat, qw, oc, C);
+    if (g_gemm_provider) provider_gemm(M, N, K, mat, qw, oc, C);
+    else gemm_rows(M, N, K, mat, qw, oc, C);
     if (acc) memcpy(acc + (int64_t)i * M * N, C, sizeof(int32_t) * (size_t)M * N);
     orc_down_scale(hwc, C, (int64_t)M * N, s_in, s_w, s_out, zp_out);
     uint8_t* o = out + (int64_t)i * N * M; /* transpose, src/conv2d.cc:51-61 */
@@ -254,6 +276,8 @@ void orc_linear_u8(const uint8_t* in, int m, int k, const int8_t* qw,
   int32_t* C = (int32_t*)malloc(sizeof(int32_t) * (size_t)m * n);
   int32_t* oc = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
   orc_linear_offsets(qw, n, k, zp_in, oc);
+  if (g_gemm_provider) provider_gemm(m, n, k, in, qw, oc, C);
+  else
 #pragma omp parallel
   {
 #ifdef _OPENMP

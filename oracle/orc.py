@@ -174,3 +174,42 @@ def set_num_threads(n):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def use_mkl(path=None):
+    """Route the contraction of conv2d()/linear() through the reference's own GEMM provider, Intel MKL's
+    cblas_gemm_s8u8s32, if its runtime is installed (this image: /opt/conda/lib/libmkl_rt.so.1; $I8IE_MKL_RT
+    overrides).  For the timed CPU baseline only.  Returns MKL's version string, or None when the runtime is
+    absent or does not reproduce the exact integer results on this host (then nothing changes).  Load it in a
+    process that has not imported torch (torch carries its own MKL)."""
+    import os
+
+    path = path or os.environ.get("I8IE_MKL_RT", "/opt/conda/lib/libmkl_rt.so.1")
+    if not os.path.exists(path):
+        return None
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")  # the oracle's OpenMP is libgomp (SURVEY.md Appendix B)
+    try:
+        mkl = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        fn = C.cast(mkl.cblas_gemm_s8u8s32, C.c_void_p)
+    except (OSError, AttributeError):
+        return None
+    lib().orc_set_gemm_provider(fn)
+    rng = np.random.default_rng(1)
+    ok = True
+    for (m, k, n, extreme) in ((64, 363, 96, True), (33, 4096, 40, False), (7, 9216, 16, True)):
+        a = rng.integers(0, 256, (m, k), dtype=np.uint8)
+        b = rng.integers(-128, 128, (n, k), dtype=np.int8)
+        if extreme:
+            a[...] = 255
+            b[::2], b[1::2] = 127, -128
+        oc = rng.integers(-1000, 1000, n).astype(np.int32)
+        got = np.empty((m, n), np.int32)
+        lib().orc_gemm_u8s8s32_provider(m, n, k, _p(a), _p(b), _p(oc), _p(got))
+        ok = ok and np.array_equal(got, gemm_u8s8s32(a, b, oc))
+    if not ok:  # e.g. an int16-saturating vpmaddubsw path on a non-VNNI / non-Intel host
+        lib().orc_set_gemm_provider(None)
+        return None
+    buf = C.create_string_buffer(256)
+    mkl.mkl_get_version_string(buf, 256)
+    use_mkl.handle = mkl
+    return buf.value.decode().strip()
