@@ -127,7 +127,10 @@ def main():
     cx.synchronize()
     h2d_ms = (time.perf_counter() - t_h2d0) * 1e3
     if use_dist:
-        stage = torch.empty((stop - start, 10), dtype=torch.float32, device="cuda")
+        # logits of batch i wait here for the gather; two buffers so that batch i + 1 can be written meanwhile
+        stage = [torch.empty((stop - start, 10), dtype=torch.float32, device="cuda") for _ in range(2)]
+        side = torch.cuda.Stream()          # gather + read-back run here, beside the next batch's kernels
+        gathered = [None, None]             # event behind the last gather that read stage[k]
 
     state = {"correct": 0, "logits": None}
     if use_dist and rank == 0:
@@ -140,16 +143,25 @@ def main():
         y = net(x_dev)
         if not use_dist:
             return y.numpy_async()
-        cx.copy_to_ptr(y.data, stage.data_ptr())
-        full = gather(stage)  # RCCL all-gather, stream-ordered behind the kernels
+        k = tick["i"] & 1
+        tick["i"] += 1
+        main = torch.cuda.current_stream()
+        if gathered[k] is not None:
+            main.wait_event(gathered[k])   # the gather of two batches ago has finished reading stage[k]
+        cx.copy_to_ptr(y.data, stage[k].data_ptr())
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):       # off the compute stream: the next batch does not wait for the collective
+            side.wait_event(ready)
+            full = gather(stage[k])         # RCCL all-gather of the per-shard logits
+            if rank == 0:
+                host_logits[k].copy_(full, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        gathered[k] = ev
         if rank != 0:
             return None
-        buf = host_logits[tick["i"] & 1]
-        tick["i"] += 1
-        buf.copy_(full, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        return buf, ev
+        return host_logits[k], ev
 
     def consume(h):
         """Wait for one batch's logits, top-1 on the host (the reference's argmax + compare)."""
