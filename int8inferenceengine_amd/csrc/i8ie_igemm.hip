@@ -932,7 +932,9 @@ int launch_tile_var(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, d
   int bn = a.N <= 32 ? 32 : a.N <= 64 ? 64 : a.N <= 96 ? 96 : 128;
   if (AMODE == 0 && bn == 128) {
     if (tiles_m * ((a.N + 127) / 128) < 512) bn = 64;
-    if (tiles_m * ((a.N + 63) / 64) < 256) bn = 32;
+    // (with split-K the K slices already fill the chip: 64-wide tiles then halve the activation re-reads;
+    // measured 0.047 vs 0.052 ms for fc6 + fc7 at 125 rows)
+    if (tiles_m * ((a.N + 63) / 64) < 256 && a.ksplit <= 1) bn = 32;
   }
   if (bn == 32)
     return launch_cfg<AMODE, 4, 1, 1, 1, BIAS, ACC, VAR>(ctx, a, AMODE ? "igemm_conv_128x32" : "igemm_lin_128x32", kbytes,
