@@ -1119,6 +1119,23 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   return accd ? launch_tile<1, false, true>(ctx, a, kb, ops, bytes) : launch_tile<1, false, false>(ctx, a, kb, ops, bytes);
 }
 
+// the Linear epilogue over [slices][M][N] INT32 partial slabs (slice 0 carries oc'), for i8ie_skinny.hip
+int i8ie_launch_splitk_reduce(i8ie_ctx* ctx, const int32_t* partial, int slices, int M, int N, const float* biasf,
+                              float s_in, float s_w, float s_out, int zp_out, int relu, uint8_t* out, int32_t* acc) {
+  Requant rq{};
+  rq.sa = s_in; rq.sb = s_w; rq.sc = s_out; rq.zpf = (float)zp_out;
+  const double ms = (double)s_in * (double)s_w / (double)s_out;
+  rq.ms = (float)ms;
+  rq.fast = (s_in > 1e-30f && s_w > 1e-30f && s_out > 1e-30f && s_in < 1e30f && s_w < 1e30f && s_out < 1e30f &&
+             ms > 1e-30 && ms < 1e30) ? 1 : 0;
+  I8ieProfScope prof(ctx, "splitk_reduce", 0.0, 4.0 * slices * M * N + (double)M * N);
+  const int64_t quads = ((int64_t)M * N + 3) / 4;
+  splitk_reduce_kernel<<<cap_grid(quads, 256), 256, 0, ctx->stream>>>(partial, slices, M, N, biasf, rq,
+                                                                      relu ? zp_out : 0, out, acc);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
 int i8ie_launch_finish_offsets(i8ie_ctx* ctx, const int32_t* oc, const int32_t* wsum, const int8_t* qb, float s_in,
                                int n, int32_t* ocp, float* biasf) {
   finish_offsets_kernel<<<(n + 63) / 64, 64, 0, ctx->stream>>>(oc, wsum, qb, s_in, n, ocp, biasf);

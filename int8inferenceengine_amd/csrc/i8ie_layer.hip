@@ -46,6 +46,12 @@ struct I8ieSmallNCall {
   float* out_f32;
 };
 int i8ie_smalln_max_features();
+int i8ie_launch_frag_pack(i8ie_ctx* ctx, const int8_t* B, void* Bf, int Npad, int Kpad);
+int i8ie_skinny_plan(int m, int n, int Kpad, int* nstep, int* slices);
+int i8ie_launch_linear_skinny(i8ie_ctx* ctx, const uint8_t* A, size_t lda, int m, const void* Bf, int Kpad, int Npad,
+                              int n, const int32_t* ocp, int32_t* partial, int nstep, int slices);
+int i8ie_launch_splitk_reduce(i8ie_ctx* ctx, const int32_t* partial, int slices, int M, int N, const float* biasf,
+                              float s_in, float s_w, float s_out, int zp_out, int relu, uint8_t* out, int32_t* acc);
 int i8ie_launch_linear_smalln(i8ie_ctx* ctx, const I8ieSmallNCall& c);
 int i8ie_launch_repack_smallc(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int c, int h, int w, int Hp,
                               int Wg, int ph, int pw, int zp, int rebias);
@@ -198,6 +204,9 @@ struct i8ie_layer {
   int8_t* Bpack = nullptr;  // [Npad][Kpad] zero padded, reference K order (Linear; conv path F)
   int8_t* Bperm = nullptr;  // Linear fed by an NHWC-flattened activation: Bpack with K reordered (h, w, c)
   int perm_c = 0, perm_hw = 0;
+  void* Bfrag = nullptr;       // Bpack in MFMA fragment order (few-row kernel, i8ie_skinny.hip), built on first use
+  void* Bfrag_perm = nullptr;  // the same of Bperm
+  bool bfrag_perm_valid = false, bfrag_valid = false;
   int path = PATH_F;        // conv: PATH_A / PATH_B / PATH_F
   int8_t* Bpack2 = nullptr; // conv paths A/B: [Npad][Kpad2], K ordered (kh, kw, c) / grouped
   int K2 = 0, Kpad2 = 0;    // valid / padded K of Bpack2 (bytes)
@@ -515,6 +524,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
         I8IE_TRY(i8ie_launch_permute_k(ctx, L->Bpack, L->Bperm, L->Npad, L->Kpad, L->K, L->K / hw, hw));
         L->perm_c = L->K / hw;
         L->perm_hw = hw;
+        L->bfrag_perm_valid = false;
       }
       panel = L->Bperm;
     }
@@ -531,6 +541,25 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
     if (out_f32 != nullptr) {  // general shape: the ordinary forward, then the dequantize kernel
       I8IE_TRY(layer_forward_impl(L, in, in_layout, 0, m, h, w, s_in, zp_in, relu, out, I8IE_LAYOUT_NCHW, 0, acc, nullptr));
       return i8ie_dequantize_u8_f32(ctx, out, out_f32, (int64_t)m * L->n, L->s_out, L->zp_out);
+    }
+    int sk_steps = 0, sk_slices = 0;
+    static const bool no_skinny = std::getenv("I8IE_NO_SKINNY") != nullptr;  // A/B aid
+    if (!force_fallback(ctx) && !need_pad && !no_skinny && ctx->variant == 0 &&
+        i8ie_skinny_plan(m, L->n, L->Kpad, &sk_steps, &sk_slices)) {
+      // few input rows: activations' K slice resident in LDS, weights streamed once in fragment order
+      const bool perm = panel == L->Bperm && L->Bperm != nullptr;
+      void** frag = perm ? &L->Bfrag_perm : &L->Bfrag;
+      if (*frag == nullptr) I8IE_TRY(i8ie_malloc(ctx, (size_t)L->Npad * L->Kpad, frag));
+      if (perm ? !L->bfrag_perm_valid : !L->bfrag_valid) {
+        I8IE_TRY(i8ie_launch_frag_pack(ctx, panel, *frag, L->Npad, L->Kpad));
+        (perm ? L->bfrag_perm_valid : L->bfrag_valid) = true;
+      }
+      const size_t part_bytes = (size_t)sk_slices * m * L->n * 4;
+      I8IE_TRY(i8ie_ws_reserve(ctx, part_bytes));
+      I8IE_TRY(i8ie_launch_linear_skinny(ctx, in, (size_t)L->K, m, *frag, L->Kpad, L->Npad, L->n, L->ocp,
+                                         (int32_t*)ctx->ws, sk_steps, sk_slices));
+      return i8ie_launch_splitk_reduce(ctx, (const int32_t*)ctx->ws, sk_slices, m, L->n, L->biasf, s_in, L->s_w,
+                                       L->s_out, L->zp_out, relu, out, acc);
     }
     if (force_fallback(ctx)) {
       if (need_pad) I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->Kpad));
@@ -730,6 +759,8 @@ int i8ie_layer_destroy(i8ie_layer* L) {
   i8ie_free(ctx, L->oc);
   i8ie_free(ctx, L->ocp);
   if (L->Bperm) i8ie_free(ctx, L->Bperm);
+  if (L->Bfrag) i8ie_free(ctx, L->Bfrag);
+  if (L->Bfrag_perm) i8ie_free(ctx, L->Bfrag_perm);
   i8ie_free(ctx, L->biasf);
   delete L;
   return I8IE_OK;
