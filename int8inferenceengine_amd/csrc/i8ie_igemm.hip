@@ -448,19 +448,52 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_u8s8_kernel(IgemmArgs p, in
   }
 
   if (AMODE == 0 && p.ksplit > 1) {  // split-K: raw INT32 partial sums, finished by splitk_reduce_kernel
+    // The tile leaves through LDS, a pass of PR rows at a time, so that the slab is written in row segments of
+    // BN * 4 bytes (one dword per lane and row was ~64 scattered line requests per wave-instruction).
     int32_t* slab = p.partial + (size_t)blockIdx.y * p.M * p.N;
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
+    constexpr int CTP = BN + 4;  // ints per staged row: 16-byte aligned, conflict-free 16-byte column writes
+    constexpr int PR = (NST * STAGE) / (CTP * 4) / 32 * 32 < BM ? (NST * STAGE) / (CTP * 4) / 32 * 32 : BM;
+    static_assert(PR >= 32, "at least one MFMA row tile per pass");
+    int* ct = reinterpret_cast<int*>(smem);
+    const int hh2 = lane >> 5;
+    for (int r0 = 0; r0 < BM; r0 += PR) {
+      if (r0 > 0) __syncthreads();  // the previous pass has been read out
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) {
-        const int grow = m0 + (wm * TM + mi) * 32 + (lane & 31);
+        const int lrow = (wm * TM + mi) * 32 + (lane & 31);
+        if (lrow >= r0 && lrow < r0 + PR) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int gcol = n0 + (wn * TN + ni) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (grow < p.M && gcol < p.N)
-            slab[(size_t)grow * p.N + gcol] = acc[mi][ni][r] + (blockIdx.y == 0 ? p.ocp[gcol] : 0);
+          for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int lcol = (wn * TN + ni) * 32 + 8 * g + 4 * hh2;
+              const int gcol = n0 + lcol;
+              int4 o = make_int4(0, 0, 0, 0);
+              if (blockIdx.y == 0 && gcol < p.N) o = *reinterpret_cast<const int4*>(p.ocp + gcol);  // padded to Npad
+              *reinterpret_cast<int4*>(ct + (lrow - r0) * CTP + lcol) =
+                  make_int4(acc[mi][ni][g * 4 + 0] + o.x, acc[mi][ni][g * 4 + 1] + o.y, acc[mi][ni][g * 4 + 2] + o.z,
+                            acc[mi][ni][g * 4 + 3] + o.w);
+            }
         }
       }
+      __syncthreads();
+      if ((p.N & 3) == 0) {
+        constexpr int CPR4 = BN / 4;
+        for (int idx = tid; idx < PR * CPR4; idx += NT) {
+          const int row = idx / CPR4, ch = idx - row * CPR4;
+          const int grow = m0 + r0 + row, gcol = n0 + ch * 4;
+          if (r0 + row < BM && grow < p.M && gcol < p.N)
+            *reinterpret_cast<int4*>(slab + (size_t)grow * p.N + gcol) =
+                *reinterpret_cast<const int4*>(ct + row * CTP + ch * 4);
+        }
+      } else {
+        for (int idx = tid; idx < PR * BN; idx += NT) {
+          const int row = idx / BN, col = idx - row * BN;
+          const int grow = m0 + r0 + row, gcol = n0 + col;
+          if (r0 + row < BM && grow < p.M && gcol < p.N) slab[(size_t)grow * p.N + gcol] = ct[row * CTP + col];
+        }
+      }
+    }
     return;
   }
 
