@@ -543,8 +543,10 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
       return i8ie_dequantize_u8_f32(ctx, out, out_f32, (int64_t)m * L->n, L->s_out, L->zp_out);
     }
     int sk_steps = 0, sk_slices = 0;
-    static const bool no_skinny = std::getenv("I8IE_NO_SKINNY") != nullptr;  // A/B aid
-    if (!force_fallback(ctx) && !need_pad && !no_skinny && ctx->variant == 0 &&
+    // opt-in ($I8IE_SKINNY=1): once the tiled split-K kernel wrote its partial tiles as row segments it became
+    // the faster one even at m = 125 (fc6 + fc7: 33 us against 42 us), see DESIGN.md
+    static const bool use_skinny = std::getenv("I8IE_SKINNY") != nullptr;
+    if (!force_fallback(ctx) && !need_pad && use_skinny && ctx->variant == 0 &&
         i8ie_skinny_plan(m, L->n, L->Kpad, &sk_steps, &sk_slices)) {
       // few input rows: activations' K slice resident in LDS, weights streamed once in fragment order
       const bool perm = panel == L->Bperm && L->Bperm != nullptr;

@@ -189,9 +189,9 @@ int i8ie_launch_frag_pack(i8ie_ctx* ctx, const int8_t* B, void* Bf, int Npad, in
 // Plan: k-steps per slice (multiple of 4, <= 36: 144 KiB of LDS) and the slice count, so that the grid has about
 // one block per CU.  Returns 0 when the shape does not suit this kernel.
 int i8ie_skinny_plan(int m, int n, int Kpad, int* nstep, int* slices) {
-  // measured on AlexNet fc6 / fc7 (tools: bench.py --batch 125 / 250 / 500, I8IE_NO_SKINNY=1 for the tiled path):
-  // one row block (m <= 128) 37 + 16 us against 47 + 20 us; from 250 rows on the tiled split-K kernel is faster
-  // (each further row block streams the weights again), so this kernel takes the single-row-block case only
+  // measured on AlexNet fc6 / fc7 (bench.py --batch 125 / 250 / 500): one row block (m <= 128) 37 us, against 47 us
+  // for the tiled split-K kernel while that still stored its partial tiles a dword per lane and row, and against
+  // 33 us once it stored row segments too.  Kept as an opt-in variant ($I8IE_SKINNY=1, single row block only).
   if (m < 1 || m > 128 || n < 64 || Kpad < 512) return 0;
   const int ksteps = Kpad / 32;
   const int groups = ((n + 31) / 32 + 3) / 4, mblocks = (m + 127) / 128;
