@@ -1,0 +1,34 @@
+// i8ie_calls.h -- argument blocks passed between the translation units of libi8ie_hip.so
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+struct i8ie_ctx;
+
+// one contraction launch: Linear (amode 0) or implicit-GEMM Conv2d over bordered NHWC (amode 1)
+struct I8ieIgemmCall {
+  const uint8_t* A;   // amode 0: [M][lda]; amode 1: window origin of pixel (0,0) in a bordered NHWC input
+  size_t a_bytes;     // bytes readable from A
+  int amode;
+  long lda;
+  int M, Kchunks;
+  int Hp, Wp, C, KH, KW, sh, sw, OH, OW;  // amode 1: physical input dims, kernel, strides, output dims
+  const int8_t* B;
+  int Kpad, Npad, N;
+  const int32_t* ocp;
+  const float* biasf;
+  float s_in, s_w, s_out;
+  int zp_out, relu;
+  uint8_t* out;
+  int ob;  // physical border of the NHWC output (amode 1 only)
+  int32_t* acc;
+  double Ktrue;
+  int ksplit;        // amode 0 only: > 1 = split K over that many slices (partial must hold ksplit*M*N int32)
+  int32_t* partial;
+};
+int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
+
+// i8ie_pp.hip: the persistent ping-pong form of the amode-1 contraction (large convolutions).
+// Returns 1 when it took the launch, 0 when the shape is not its (the caller then runs the tiled kernel),
+// < 0 on error.
+int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);

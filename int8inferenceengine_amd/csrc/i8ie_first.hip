@@ -20,41 +20,18 @@
 #include <type_traits>
 
 #include "i8ie_internal.h"
+#include "i8ie_requant.h"
 
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-struct FRequant {
-  float sa, sb, sc, zpf, ms;
-  int fast;
-};
-
-__device__ __forceinline__ int frequant_exact(float cf, const FRequant& q, int lo) {
-  const float deq = (cf * q.sa) * q.sb;  // src/quantize_utils.cc:30-33
-  const float v = deq / q.sc + q.zpf;
-  const int u = (v >= 255.0f) ? 255 : ((v < 0.0f) ? 0 : (int)v);
-  return u > lo ? u : lo;
-}
-// Four accumulators -> one packed dword.  See requant_pack4 in i8ie_igemm.hip for the proof that the
-// fast path equals the reference sequence; one (rare) branch per dword instead of two per element.
+using FRequant = I8ieRequant;  // i8ie_requant.h
 __device__ __forceinline__ uint32_t frequant_pack4(int c0, int c1, int c2, int c3, const FRequant& q, int lo,
                                                    float lof) {
   const int c[4] = {c0, c1, c2, c3};
-  uint32_t packed = 0;
-  float worst = q.fast ? 1.0f : 0.0f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float e = __builtin_fmaf((float)c[r], q.ms, q.zpf - 0.5f);
-    packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(e, lof), r, packed);
-    worst = __builtin_fminf(worst, __builtin_fabsf(__builtin_amdgcn_fractf(e) - 0.5f));
-  }
-  if (worst >= 1.220703125e-4f) return packed;  // 2^-13 > 9.2e-5, the proven error bound
-  packed = 0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) packed |= (uint32_t)frequant_exact((float)c[r], q, lo) << (8 * r);
-  return packed;
+  return i8ie_requant_pack4(c, q, lo, lof);
 }
 
 constexpr int kMaxKS = 24;
@@ -376,11 +353,7 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
   a.bands_per_img = (c.OH + RB - 1) / RB;
   a.total_bands = a.bands_per_img * c.n;
   a.B = c.B; a.Kpad = c.Kpad; a.N = c.N; a.ocp = c.ocp;
-  a.rq.sa = c.s_in; a.rq.sb = c.s_w; a.rq.sc = c.s_out; a.rq.zpf = (float)c.zp_out;
-  const double ms = (double)c.s_in * (double)c.s_w / (double)c.s_out;
-  a.rq.ms = (float)ms;
-  a.rq.fast = (c.s_in > 1e-30f && c.s_w > 1e-30f && c.s_out > 1e-30f && c.s_in < 1e30f && c.s_w < 1e30f &&
-               c.s_out < 1e30f && ms > 1e-30 && ms < 1e30) ? 1 : 0;
+  a.rq = i8ie_make_requant(c.s_in, c.s_w, c.s_out, c.zp_out);
   a.relu_lo = c.relu ? c.zp_out : 0;
   a.out = c.out; a.ob = c.ob;
   const int ks_needed = (c.K2 + 31) / 32;

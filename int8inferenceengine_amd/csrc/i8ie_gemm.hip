@@ -17,6 +17,7 @@
 // are issued before the current tile's MFMAs) into a 16-B-chunk XOR-swizzled
 // LDS image that makes the ds_read_b128 fragment reads conflict-free.
 #include "i8ie_internal.h"
+#include "i8ie_requant.h"
 
 namespace {
 
@@ -31,10 +32,8 @@ __device__ __forceinline__ int lds_chunk_off(int row, int c) {
 }
 
 __device__ __forceinline__ uint8_t requant_u8(int c, float sa, float sb, float sc, float zpf) {
-  // src/quantize_utils.cc:30-33
-  float deq = ((float)c * sa) * sb;
-  float q = deq / sc + zpf;
-  return (q >= 255.0f) ? (uint8_t)255 : ((q < 0.0f) ? (uint8_t)0 : (uint8_t)(int)q);
+  const I8ieRequant q{sa, sb, sc, zpf, 0.0f, I8IE_RQ_EXACT};  // i8ie_requant.h: the exact sequence only
+  return (uint8_t)i8ie_requant_exact((float)c, q, 0);
 }
 
 template <int WM, int WN, int TM, int TN>

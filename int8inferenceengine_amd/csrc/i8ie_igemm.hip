@@ -28,6 +28,8 @@
 #include <type_traits>
 
 #include "i8ie_internal.h"
+#include "i8ie_calls.h"
+#include "i8ie_requant.h"
 
 namespace {
 
@@ -37,44 +39,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int BK2 = 128;   // bytes of K per stage: 8 chunks of 16 B = 4 MFMA k-steps
 constexpr int LROW = 144;  // LDS row stride
 
-struct Requant {
-  float sa, sb, sc, zpf, ms;
-  int fast;
-};
-
-// src/quantize_utils.cc:30-33, the exact sequence
-__device__ __forceinline__ int requant_exact(float cf, const Requant& q, int lo) {
-  const float deq = (cf * q.sa) * q.sb;
-  const float v = deq / q.sc + q.zpf;
-  const int u = (v >= 255.0f) ? 255 : ((v < 0.0f) ? 0 : (int)v);
-  return u > lo ? u : lo;
-}
-
-// e = fma(cf, ms, zp - 0.5), ms = fl(s_in*s_w/s_out): an estimate of (reference value v) - 0.5.
-// While -1 < v < 256, |v - (e + 0.5)| < 9.2e-5 (reference: 3 roundings on |C*s_in*s_w/s_out| < 256
-// and one on |v| < 257; e: one rounding of ms, one of the fma).  So if e is further than 2^-13
-// from every half-integer, v lies strictly inside the unit interval [k, k+1) with k = rne(e), and
-// the reference's trunc + clamp equals sat_u8(rne(e)), which is exactly what v_cvt_pk_u8_f32
-// computes (round-to-nearest-even, saturate to [0, 255], insert into byte r).  Outside (-1, 256)
-// both sides clamp, with the same margin.  Anything closer to a half-integer replays the exact
-// sequence.  relu (max with zp_out) commutes with the monotone rounding: rne(max(e, lo)) for the
-// integer lo.
+using Requant = I8ieRequant;  // i8ie_requant.h: the exact sequence, the guarded estimate and its proof
+__device__ __forceinline__ int requant_exact(float cf, const Requant& q, int lo) { return i8ie_requant_exact(cf, q, lo); }
 __device__ __forceinline__ uint32_t requant_pack4(const int (&c)[4], const Requant& q, int lo, float lof) {
-  // branch-free fast path for the four bytes of one dword; `worst` = smallest distance of any of the
-  // four estimates to a rounding boundary (0 when the fast path is disabled); one rare branch per dword
-  uint32_t packed = 0;
-  float worst = q.fast ? 1.0f : 0.0f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float e = __builtin_fmaf((float)c[r], q.ms, q.zpf - 0.5f);
-    packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(e, lof), r, packed);
-    worst = __builtin_fminf(worst, __builtin_fabsf(__builtin_amdgcn_fractf(e) - 0.5f));
-  }
-  if (worst >= 1.220703125e-4f) return packed;  // 2^-13 > 9.2e-5, the proven error bound
-  packed = 0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) packed |= (uint32_t)requant_exact((float)c[r], q, lo) << (8 * r);
-  return packed;
+  return i8ie_requant_pack4(c, q, lo, lof);
 }
 
 struct IgemmArgs {
@@ -1019,26 +987,6 @@ int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, doubl
 }  // namespace
 
 // ---- entry points used by i8ie_layer.hip ---------------------------------------------------
-struct I8ieIgemmCall {
-  const uint8_t* A;   // AMODE 0: [M][lda]; AMODE 1: window origin of pixel (0,0) in a bordered NHWC input
-  size_t a_bytes;     // bytes readable from A
-  int amode;
-  long lda;
-  int M, Kchunks;
-  int Hp, Wp, C, KH, KW, sh, sw, OH, OW;  // AMODE 1: physical input dims, kernel, strides, output dims
-  const int8_t* B;
-  int Kpad, Npad, N;
-  const int32_t* ocp;
-  const float* biasf;
-  float s_in, s_w, s_out;
-  int zp_out, relu;
-  uint8_t* out;
-  int ob;  // physical border of the NHWC output (AMODE 1 only)
-  int32_t* acc;
-  double Ktrue;
-  int ksplit;        // AMODE 0 only: > 1 = split K over that many slices (partial must hold ksplit*M*N int32)
-  int32_t* partial;
-};
 
 // The gathers address A with 32-bit buffer offsets.  A batch whose activations exceed that range (288 GB of
 // HBM hold far more than 4 GiB) runs as several launches over whole images / rows; $I8IE_IGEMM_CHUNK_BYTES
@@ -1090,6 +1038,11 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     }
     return I8IE_OK;
   }
+  // large convolutions: the persistent ping-pong kernel (i8ie_pp.hip); variant 11 keeps the tiled kernel
+  if (c.amode == 1 && (ctx->variant == 0 || ctx->variant == 20)) {
+    const int took = i8ie_pp_try_launch(ctx, c);
+    if (took != 0) return took < 0 ? took : I8IE_OK;
+  }
   IgemmArgs a{};
   a.A = c.A;
   a.a_bytes = (unsigned)c.a_bytes;
@@ -1110,12 +1063,7 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.N = c.N;
   a.ocp = c.ocp;
   a.biasf = c.biasf;
-  a.rq.sa = c.s_in; a.rq.sb = c.s_w; a.rq.sc = c.s_out; a.rq.zpf = (float)c.zp_out;
-  const double ms = (double)c.s_in * (double)c.s_w / (double)c.s_out;
-  a.rq.ms = (float)ms;
-  // fast path only for ordinary positive finite scales; anything else takes the exact sequence
-  a.rq.fast = (c.s_in > 1e-30f && c.s_w > 1e-30f && c.s_out > 1e-30f && c.s_in < 1e30f && c.s_w < 1e30f &&
-               c.s_out < 1e30f && ms > 1e-30 && ms < 1e30) ? 1 : 0;
+  a.rq = i8ie_make_requant(c.s_in, c.s_w, c.s_out, c.zp_out);
   a.relu_lo = c.relu ? c.zp_out : 0;
   a.out = c.out;
   a.ob = c.amode == 1 ? c.ob : 0;
@@ -1155,12 +1103,7 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
 // the Linear epilogue over [slices][M][N] INT32 partial slabs (slice 0 carries oc'), for i8ie_skinny.hip
 int i8ie_launch_splitk_reduce(i8ie_ctx* ctx, const int32_t* partial, int slices, int M, int N, const float* biasf,
                               float s_in, float s_w, float s_out, int zp_out, int relu, uint8_t* out, int32_t* acc) {
-  Requant rq{};
-  rq.sa = s_in; rq.sb = s_w; rq.sc = s_out; rq.zpf = (float)zp_out;
-  const double ms = (double)s_in * (double)s_w / (double)s_out;
-  rq.ms = (float)ms;
-  rq.fast = (s_in > 1e-30f && s_w > 1e-30f && s_out > 1e-30f && s_in < 1e30f && s_w < 1e30f && s_out < 1e30f &&
-             ms > 1e-30 && ms < 1e30) ? 1 : 0;
+  const Requant rq = i8ie_make_requant(s_in, s_w, s_out, zp_out);
   I8ieProfScope prof(ctx, "splitk_reduce", 0.0, 4.0 * slices * M * N + (double)M * N);
   const int64_t quads = ((int64_t)M * N + 3) / 4;
   splitk_reduce_kernel<<<cap_grid(quads, 256), 256, 0, ctx->stream>>>(partial, slices, M, N, biasf, rq,
@@ -1242,7 +1185,8 @@ int i8ie_launch_linear_smalln(i8ie_ctx* ctx, const I8ieSmallNCall& c) {
   SmallNArgs a{};
   a.A = c.A; a.lda = c.lda; a.M = c.M; a.K = c.K; a.B = c.B; a.Kpad = c.Kpad; a.N = c.N;
   a.ocp = c.ocp; a.biasf = c.biasf;
-  a.rq.sa = c.s_in; a.rq.sb = c.s_w; a.rq.sc = c.s_out; a.rq.zpf = (float)c.zp_out; a.rq.ms = 0.0f; a.rq.fast = 0;
+  a.rq = i8ie_make_requant(c.s_in, c.s_w, c.s_out, c.zp_out);
+  a.rq.fast = I8IE_RQ_EXACT;
   a.relu_lo = c.relu ? c.zp_out : 0;
   a.out = c.out; a.acc = c.acc; a.out_f32 = c.out_f32; a.dq_scale = c.s_out; a.dq_zp = c.zp_out;
   I8ieProfScope prof(ctx, "linear_smalln_dot4", 2.0 * c.M * c.N * c.K, (double)c.M * c.K + (double)c.N * c.K + 5.0 * c.M * c.N);

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "i8ie_internal.h"
+#include "i8ie_calls.h"
 
 int i8ie_launch_pad_rows(i8ie_ctx* ctx, const void* src, int rows, int k, void* dst, int rows_pad, int k_pad,
                          int fill);
@@ -59,27 +60,7 @@ int i8ie_launch_fill_border(i8ie_ctx* ctx, uint8_t* out, int n, int c, int h, in
 int i8ie_launch_maxpool_nhwc(i8ie_ctx* ctx, const uint8_t* in, int ib, uint8_t* out, int ob, int n, int c, int h,
                              int w, int k, int s, int relu_zp);
 
-struct I8ieIgemmCall {
-  const uint8_t* A;
-  size_t a_bytes;
-  int amode;
-  long lda;
-  int M, Kchunks;
-  int Hp, Wp, C, KH, KW, sh, sw, OH, OW;
-  const int8_t* B;
-  int Kpad, Npad, N;
-  const int32_t* ocp;
-  const float* biasf;
-  float s_in, s_w, s_out;
-  int zp_out, relu;
-  uint8_t* out;
-  int ob;
-  int32_t* acc;
-  double Ktrue;
-  int ksplit;
-  int32_t* partial;
-};
-int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
+
 
 struct I8ieFirstCall {
   const float* x;

@@ -1,0 +1,114 @@
+// i8ie_requant.h -- the one requantiser of libi8ie_hip.so (every kernel's epilogue includes this file).
+//
+// Reference: down_scale, src/quantize_utils.cc:27-36
+//     deq = ((float)C * s_in) * s_w;  q = deq / s_out + (float)zp_out;
+//     out = q >= 255 ? 255 : (q < 0 ? 0 : (u8)q)                      (IEEE fp32, no contraction)
+// optionally followed by relu<u8> (src/functional.cc:15-26): out = max(out, zp_out).
+//
+// Three evaluation modes, all bit-identical to that sequence:
+//   I8IE_RQ_EXACT    the sequence itself.
+//   I8IE_RQ_GUARDED  e = fma((float)C, ms, zp - 0.5), ms = fl(s_in*s_w/s_out), packed with v_cvt_pk_u8_f32
+//                    (round-to-nearest-even, saturate); any dword holding a value closer than 2^-13 to a
+//                    rounding boundary replays the exact sequence (error analysis below).
+//   I8IE_RQ_PROVEN   the same estimate with NO guard.  Both functions are monotone step functions of the
+//                    integer C, so they are equal on every int32 iff their 255 step positions coincide;
+//                    i8ie_requant_prove() finds each step of both by bisection over C on the host (about
+//                    16 k evaluations) before a kernel is allowed to run in this mode.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+enum { I8IE_RQ_EXACT = 0, I8IE_RQ_GUARDED = 1, I8IE_RQ_PROVEN = 2 };
+
+struct I8ieRequant {
+  float sa, sb, sc, zpf, ms;
+  int fast;  // I8IE_RQ_*
+};
+
+// src/quantize_utils.cc:30-33, the exact sequence (+ relu lower bound `lo`, 0 when relu is not fused)
+__host__ __device__ __forceinline__ int i8ie_requant_exact(float cf, const I8ieRequant& q, int lo) {
+  const float deq = (cf * q.sa) * q.sb;
+  const float v = deq / q.sc + q.zpf;
+  const int u = (v >= 255.0f) ? 255 : ((v < 0.0f) ? 0 : (int)v);
+  return u > lo ? u : lo;
+}
+
+#if defined(__HIPCC__)
+// e = fma(cf, ms, zp - 0.5): an estimate of (reference value v) - 0.5.  While -1 < v < 256,
+// |v - (e + 0.5)| < 9.2e-5 (reference: 3 roundings on |C*s_in*s_w/s_out| < 256 and one on |v| < 257; e: one
+// rounding of ms, one of the fma).  So if e is further than 2^-13 from every half-integer, v lies strictly
+// inside the unit interval [k, k+1) with k = rne(e), and the reference's trunc + clamp equals sat_u8(rne(e)),
+// which is what v_cvt_pk_u8_f32 computes.  Outside (-1, 256) both sides clamp, with the same margin.  relu
+// (max with zp_out) commutes with the monotone rounding: rne(max(e, lo)) for the integer lo.
+__device__ __forceinline__ uint32_t i8ie_requant_pack4(const int (&c)[4], const I8ieRequant& q, int lo, float lof) {
+  uint32_t packed = 0;
+  float worst = q.fast ? 1.0f : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float e = __builtin_fmaf((float)c[r], q.ms, q.zpf - 0.5f);
+    packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(e, lof), r, packed);
+    worst = __builtin_fminf(worst, __builtin_fabsf(__builtin_amdgcn_fractf(e) - 0.5f));
+  }
+  if (q.fast == I8IE_RQ_PROVEN || worst >= 1.220703125e-4f) return packed;  // 2^-13 > 9.2e-5, the proven bound
+  packed = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) packed |= (uint32_t)i8ie_requant_exact((float)c[r], q, lo) << (8 * r);
+  return packed;
+}
+
+// the unguarded estimate alone (kernels compiled for I8IE_RQ_PROVEN): 4 VALU operations per value
+__device__ __forceinline__ uint32_t i8ie_requant_pack4_proven(int c0, int c1, int c2, int c3, float ms, float bias,
+                                                              float lof) {
+  uint32_t packed = 0;
+  packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(__builtin_fmaf((float)c0, ms, bias), lof), 0, packed);
+  packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(__builtin_fmaf((float)c1, ms, bias), lof), 1, packed);
+  packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(__builtin_fmaf((float)c2, ms, bias), lof), 2, packed);
+  packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(__builtin_fmaf((float)c3, ms, bias), lof), 3, packed);
+  return packed;
+}
+#endif
+
+// ---- host side --------------------------------------------------------------------------------------------
+// what the device estimate computes, restated for the host: sat_u8(rne(max(fma(cf, ms, zp - 0.5), lo)))
+inline int i8ie_requant_estimate_host(float cf, const I8ieRequant& q, int lo) {
+  float e = std::fmaf(cf, q.ms, q.zpf - 0.5f);
+  if (e < (float)lo) e = (float)lo;
+  if (!(e > 0.0f)) return 0;  // also NaN
+  if (e >= 255.0f) return 255;
+  return (int)std::nearbyintf(e);  // default rounding mode: to nearest, ties to even
+}
+
+inline I8ieRequant i8ie_make_requant(float s_in, float s_w, float s_out, int zp_out) {
+  I8ieRequant r;
+  r.sa = s_in; r.sb = s_w; r.sc = s_out; r.zpf = (float)zp_out;
+  const double ms = (double)s_in * (double)s_w / (double)s_out;
+  r.ms = (float)ms;
+  // estimate only for ordinary positive finite scales; anything else takes the exact sequence
+  r.fast = (s_in > 1e-30f && s_w > 1e-30f && s_out > 1e-30f && s_in < 1e30f && s_w < 1e30f && s_out < 1e30f &&
+            ms > 1e-30 && ms < 1e30) ? I8IE_RQ_GUARDED : I8IE_RQ_EXACT;
+  return r;
+}
+
+// True iff the unguarded estimate equals the exact sequence for EVERY int32 accumulator value.
+// Both are non-decreasing step functions of C with values in [lo, 255] (positive scales), so they are equal
+// everywhere iff they agree at both ends of the int32 range and every step sits at the same C.
+template <typename F>
+inline int64_t i8ie_first_c_reaching(F&& f, int level) {  // smallest C in int32 with f(C) >= level, or 2^31
+  int64_t lo = -2147483648LL, hi = 2147483648LL;         // invariant: f(lo - 1) < level (vacuous), f(hi) >= level
+  while (lo < hi) {
+    const int64_t mid = lo + (hi - lo) / 2;
+    if (f((float)(int32_t)mid) >= level) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+inline bool i8ie_requant_prove(const I8ieRequant& q, int lo) {
+  if (q.fast == I8IE_RQ_EXACT) return false;
+  auto ex = [&](float cf) { return i8ie_requant_exact(cf, q, lo); };
+  auto es = [&](float cf) { return i8ie_requant_estimate_host(cf, q, lo); };
+  if (ex(-2147483648.0f) != es(-2147483648.0f) || ex(2147483648.0f) != es(2147483648.0f)) return false;
+  for (int level = lo + 1; level <= 255; ++level)
+    if (i8ie_first_c_reaching(ex, level) != i8ie_first_c_reaching(es, level)) return false;
+  return true;
+}
