@@ -141,6 +141,18 @@ int i8ie_maxpool2d_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, in
 int i8ie_down_scale(i8ie_ctx* ctx, const int32_t* acc_dev, uint8_t* out_dev, int64_t n, float sa,
                     float sb, float sc, uint8_t zp_c);
 
+/* ---- host side of the requantiser (no device, no ctx) ---------------------------
+ * The large-convolution kernel requantises with a two-operation estimate
+ * fma((float)C, ms, bias) -> round-to-nearest-even -> saturate, used only after
+ * i8ie_requant_fit_host() has PROVEN it equal to down_scale (+ relu) of
+ * src/quantize_utils.cc:27-36 for every int32 accumulator (csrc/i8ie_requant.h).
+ * fit: returns 1 and the constants when such (ms, bias) exist, 0 otherwise (the
+ * kernel then keeps the guarded / exact sequence).  eval: both functions on a host
+ * array of accumulators, for tests. */
+int i8ie_requant_fit_host(float sa, float sb, float sc, int zp_c, int relu, float* ms, float* bias);
+int i8ie_requant_eval_host(float sa, float sb, float sc, int zp_c, int relu, float ms, float bias,
+                           const int32_t* acc_host, int64_t n, uint8_t* exact_host, uint8_t* estimate_host);
+
 /* ---- FP32 ops: the path taken before convert() and while calibrating -------
  * Conv2d/Linear::forward_prop(Tensor<float>&&)  src/conv2d.cc:63-98, src/fully_connected.cc:5-21
  * (cblas_sgemm + bias); relu<float>, max_pool2d<float>  src/functional.cc:5-13,36-64.

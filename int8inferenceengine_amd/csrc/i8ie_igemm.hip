@@ -1039,7 +1039,7 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     return I8IE_OK;
   }
   // large convolutions: the persistent ping-pong kernel (i8ie_pp.hip); variant 11 keeps the tiled kernel
-  if (c.amode == 1 && (ctx->variant == 0 || ctx->variant == 20)) {
+  if (c.amode == 1 && (ctx->variant == 0 || (ctx->variant >= 20 && ctx->variant < 40))) {
     const int took = i8ie_pp_try_launch(ctx, c);
     if (took != 0) return took < 0 ? took : I8IE_OK;
   }

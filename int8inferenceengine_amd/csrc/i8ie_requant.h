@@ -10,10 +10,9 @@
 //   I8IE_RQ_GUARDED  e = fma((float)C, ms, zp - 0.5), ms = fl(s_in*s_w/s_out), packed with v_cvt_pk_u8_f32
 //                    (round-to-nearest-even, saturate); any dword holding a value closer than 2^-13 to a
 //                    rounding boundary replays the exact sequence (error analysis below).
-//   I8IE_RQ_PROVEN   the same estimate with NO guard.  Both functions are monotone step functions of the
-//                    integer C, so they are equal on every int32 iff their 255 step positions coincide;
-//                    i8ie_requant_prove() finds each step of both by bisection over C on the host (about
-//                    16 k evaluations) before a kernel is allowed to run in this mode.
+//   I8IE_RQ_PROVEN   an estimate of the same form, fma((float)C, ms', bias'), with NO guard: i8ie_requant_fit()
+//                    (below) picks ms', bias' on the host and proves, by finding every step of both step
+//                    functions, that the estimate equals the exact sequence for every int32 C.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -71,15 +70,6 @@ __device__ __forceinline__ uint32_t i8ie_requant_pack4_proven(int c0, int c1, in
 #endif
 
 // ---- host side --------------------------------------------------------------------------------------------
-// what the device estimate computes, restated for the host: sat_u8(rne(max(fma(cf, ms, zp - 0.5), lo)))
-inline int i8ie_requant_estimate_host(float cf, const I8ieRequant& q, int lo) {
-  float e = std::fmaf(cf, q.ms, q.zpf - 0.5f);
-  if (e < (float)lo) e = (float)lo;
-  if (!(e > 0.0f)) return 0;  // also NaN
-  if (e >= 255.0f) return 255;
-  return (int)std::nearbyintf(e);  // default rounding mode: to nearest, ties to even
-}
-
 inline I8ieRequant i8ie_make_requant(float s_in, float s_w, float s_out, int zp_out) {
   I8ieRequant r;
   r.sa = s_in; r.sb = s_w; r.sc = s_out; r.zpf = (float)zp_out;
@@ -91,24 +81,77 @@ inline I8ieRequant i8ie_make_requant(float s_in, float s_w, float s_out, int zp_
   return r;
 }
 
-// True iff the unguarded estimate equals the exact sequence for EVERY int32 accumulator value.
-// Both are non-decreasing step functions of C with values in [lo, 255] (positive scales), so they are equal
-// everywhere iff they agree at both ends of the int32 range and every step sits at the same C.
+// ---- proof of the unguarded estimate --------------------------------------------------------------------
+// Both the exact sequence and sat_u8(rne(max(fma(cf, ms, bias), lo))) are non-decreasing step functions of the
+// integer C with values in [lo, 255] (positive scales), so they are equal on every int32 iff they agree at both
+// ends of the range and every one of the (at most 255) steps sits at the same C.  i8ie_requant_fit() finds each
+// step of the exact sequence by bisection over C, then looks for (ms, bias) whose estimate steps at exactly
+// those C: the nominal ms = fl(s_in*s_w/s_out) first, then its float neighbours (scales that are "round", like
+// 0.025 * 0.002 / 0.05, put accumulators exactly on rounding boundaries, where a neighbour of ms reproduces the
+// reference's tie-breaking and the nominal value does not).  Every candidate is verified by the same bisection
+// in float arithmetic before it is accepted; when none passes, the caller keeps the guarded mode.
 template <typename F>
 inline int64_t i8ie_first_c_reaching(F&& f, int level) {  // smallest C in int32 with f(C) >= level, or 2^31
-  int64_t lo = -2147483648LL, hi = 2147483648LL;         // invariant: f(lo - 1) < level (vacuous), f(hi) >= level
+  int64_t lo = -2147483648LL, hi = 2147483648LL;
   while (lo < hi) {
     const int64_t mid = lo + (hi - lo) / 2;
     if (f((float)(int32_t)mid) >= level) hi = mid; else lo = mid + 1;
   }
   return lo;
 }
-inline bool i8ie_requant_prove(const I8ieRequant& q, int lo) {
+inline int i8ie_estimate_host(float cf, float ms, float bias, int lo) {
+  float e = std::fmaf(cf, ms, bias);
+  if (e < (float)lo) e = (float)lo;
+  if (!(e > 0.0f)) return 0;  // also NaN
+  if (e >= 255.0f) return 255;
+  return (int)std::nearbyintf(e);  // default rounding mode: to nearest, ties to even (= v_cvt_pk_u8_f32)
+}
+// On success *ms_out, *bias_out make i8ie_requant_pack4_proven() exact for every int32 accumulator.
+inline bool i8ie_requant_fit(const I8ieRequant& q, int lo, float* ms_out, float* bias_out) {
   if (q.fast == I8IE_RQ_EXACT) return false;
   auto ex = [&](float cf) { return i8ie_requant_exact(cf, q, lo); };
-  auto es = [&](float cf) { return i8ie_requant_estimate_host(cf, q, lo); };
-  if (ex(-2147483648.0f) != es(-2147483648.0f) || ex(2147483648.0f) != es(2147483648.0f)) return false;
-  for (int level = lo + 1; level <= 255; ++level)
-    if (i8ie_first_c_reaching(ex, level) != i8ie_first_c_reaching(es, level)) return false;
-  return true;
+  int64_t thr[256];
+  for (int level = lo + 1; level <= 255; ++level) thr[level] = i8ie_first_c_reaching(ex, level);
+  const int lo_end = ex(-2147483648.0f), hi_end = ex(2147483648.0f);
+  auto verify = [&](float ms, float bias) {
+    auto es = [&](float cf) { return i8ie_estimate_host(cf, ms, bias, lo); };
+    if (es(-2147483648.0f) != lo_end || es(2147483648.0f) != hi_end) return false;
+    for (int level = lo + 1; level <= 255; ++level)
+      if (i8ie_first_c_reaching(es, level) != thr[level]) return false;
+    return true;
+  };
+  const float bias0 = q.zpf - 0.5f;
+  if (verify(q.ms, bias0)) {
+    *ms_out = q.ms;
+    *bias_out = bias0;
+    return true;
+  }
+  // a step at C = thr[level] needs fma(thr, ms, b) > level - 0.5 and fma(thr - 1, ms, b) < level - 0.5: for a
+  // given ms an interval of b; scan the float neighbours of ms outwards
+  float up = q.ms, dn = q.ms;
+  for (int step = 0; step <= 4096; ++step) {
+    for (int side = 0; side < 2; ++side) {
+      const float ms = side ? dn : up;
+      if (step == 0 && side == 1) continue;
+      double lower = -1e300, upper = 1e300;
+      for (int level = lo + 1; level <= 255; ++level) {
+        if (thr[level] >= 2147483648LL || thr[level] <= -2147483648LL) continue;  // never / always reached: ends cover it
+        const double a = (double)level - 0.5 - (double)(float)(int32_t)thr[level] * (double)ms;
+        const double b = (double)level - 0.5 - (double)(float)(int32_t)(thr[level] - 1) * (double)ms;
+        if (a > lower) lower = a;
+        if (b < upper) upper = b;
+      }
+      if (upper - lower > 1e-4) {
+        const float bias = (float)(0.5 * (lower + upper));
+        if (verify(ms, bias)) {
+          *ms_out = ms;
+          *bias_out = bias;
+          return true;
+        }
+      }
+    }
+    up = std::nextafterf(up, 3.0e38f);
+    dn = std::nextafterf(dn, 0.0f);
+  }
+  return false;
 }
