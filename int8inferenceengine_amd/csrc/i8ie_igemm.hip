@@ -1038,8 +1038,10 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     }
     return I8IE_OK;
   }
-  // large convolutions: the persistent ping-pong kernel (i8ie_pp.hip); variant 11 keeps the tiled kernel
-  if (c.amode == 1 && (ctx->variant == 0 || (ctx->variant >= 20 && ctx->variant < 40))) {
+  // The persistent ping-pong kernel (i8ie_pp.hip) is opt-in (variant 20; 21-49 are its diagnostic builds): measured
+  // on MI355X it trails the tiled kernel by 3-8 % on AlexNet conv2 / conv5 as long as activations need the u8 -> s8
+  // xor in its MFMA slots ("what bounds the ping-pong kernel"), and it pads N = 384 to 512.
+  if (c.amode == 1 && ctx->variant >= 20 && ctx->variant < 50) {
     const int took = i8ie_pp_try_launch(ctx, c);
     if (took != 0) return took < 0 ? took : I8IE_OK;
   }

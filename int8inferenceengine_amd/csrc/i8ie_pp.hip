@@ -43,8 +43,11 @@ constexpr int kHalf = 16384;   // one half-tile buffer: 128 rows x 128 B
 constexpr int kStage = 65536;  // A0 A1 B0 B1
 constexpr int kB0x = 2 * kStage;          // third B0 buffer (B0 is read in phases 1 and 4: see the schedule below)
 constexpr int kOcpOff = 2 * kStage + kHalf;
-constexpr int kOcpMax = 1024;  // features covered by the LDS copy of oc'
-constexpr int kLdsBytes = kOcpOff + kOcpMax * 4;
+constexpr int kOcpMax = 512;   // features covered by the LDS copy of oc'
+constexpr int kTabOff = kOcpOff + kOcpMax * 4;
+constexpr int kMaxP = 1536;    // output pixels per image covered by the row tables (2 x 4 B each)
+constexpr int kLdsBytes = kTabOff + 2 * 4 * kMaxP;
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 constexpr int kBN = 256;
 constexpr unsigned kRowInvalid = 0xC0000000u;  // beyond any output buffer this kernel accepts (< 2^31 bytes)
 
@@ -72,8 +75,9 @@ struct PPArgs {
 
 #define PP_BAR() asm volatile("s_barrier" ::: "memory")
 #define PP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-template <int N>
+template <int N, int DBG = 0>
 __device__ __forceinline__ void pp_wait_vm() {
+  if (DBG & 4096) return;  // (timing experiment: no counted waits at all -- results are garbage)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
@@ -123,6 +127,15 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
   for (int i = tid; i < kOcpMax; i += 512)
     reinterpret_cast<int*>(smem + kOcpOff)[i] = i < p.Npad ? p.ocp[i] : 0;
 
+  // row tables: output pixel `rem` of an image -> byte offset of its window in the input image, and of its row in
+  // the (bordered) output image: a row index then costs one division (by OH * OW) instead of two
+  for (int i = tid; i < p.OH * p.OW; i += 512) {
+    int oh, ow;
+    divmod_f(i, p.OW, p.rcpOW, oh, ow);
+    reinterpret_cast<unsigned*>(smem + kTabOff)[i] = (unsigned)(oh * p.sh) * p.row_pitch + (unsigned)(ow * p.sw) * p.C;
+    reinterpret_cast<unsigned*>(smem + kTabOff + 4 * kMaxP)[i] = (unsigned)((oh + p.ob) * p.OWp + ow + p.ob) * (unsigned)p.N;
+  }
+
   const __amdgpu_buffer_rsrc_t rsA =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.A), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB =
@@ -166,10 +179,9 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
     const int tm = t / p.tiles_n;
     int r = tm * BM + half * HR + j * 64 + prow;
     r = r < p.M ? r : p.M - 1;  // rows past M: computed, never stored
-    int img, rem, oh, ow;
+    int img, rem;
     divmod_f(r, P, p.rcpP, img, rem);
-    divmod_f(rem, p.OW, p.rcpOW, oh, ow);
-    return (unsigned)img * p.img_pitch + (unsigned)(oh * p.sh) * p.row_pitch + (unsigned)(ow * p.sw) * p.C;
+    return (unsigned)img * p.img_pitch + reinterpret_cast<const unsigned*>(smem + kTabOff)[rem];
   };
   auto b_row_off = [&](int t, int half, int j) -> unsigned {
     const int tn = t % p.tiles_n;
@@ -182,16 +194,16 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
                                              (int)voff, soff, 0, 0);
   };
   // half-tile `hb` (0 A0, 1 A1, 2 B0, 3 B1) of stage `st`: this wave's two pieces
-  auto fill_A = [&](int st, int a, const unsigned (&off)[2], unsigned koff) {
+  // piece j (0 / 1) of a half-tile: the first one goes out in the load slot, the second behind the phase's last
+  // MFMA (an LDS-DMA instruction holds its wave for ~150 cycles while the SIMD's other wave issues MFMAs, ~70
+  // when it does not: two per load slot made that slot 1.7 x the MFMA slot)
+  auto fill_A = [&](int st, int a, const unsigned (&off)[2], unsigned koff, int j) {
     if (DBG & 32) return;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      dma(rsA, st + a * kHalf + (j * 64 + wave * 8) * 128, (DBG & 128) ? ((off[j] + koff) & 0xFFFFu) : off[j] + koff, 0);
+    dma(rsA, st + a * kHalf + (j * 64 + wave * 8) * 128, (DBG & 128) ? ((off[j] + koff) & 0xFFFFu) : off[j] + koff, 0);
   };
-  auto fill_B = [&](int buf, const unsigned (&off)[2], int kt) {  // buf: LDS offset of the half-tile buffer
+  auto fill_B = [&](int buf, const unsigned (&off)[2], int kt, int j) {  // buf: LDS offset of the half-tile buffer
     if (DBG & 64) return;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) dma(rsB, buf + (j * 64 + wave * 8) * 128, (DBG & 128) ? (off[j] & 0xFFFFu) : off[j], (DBG & 128) ? 0 : kt * 128);
+    dma(rsB, buf + (j * 64 + wave * 8) * 128, (DBG & 128) ? (off[j] & 0xFFFFu) : off[j], (DBG & 128) ? 0 : kt * 128);
   };
   unsigned aA1[2], koff1;                   // cursor 1 = K tile t + 1 (A1)
   unsigned aA0[2], bB0[2], bB1[2], koff2;   // cursor 2 = K tile t + 2 (B0, A0, B1)
@@ -226,15 +238,19 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
   auto tile_rows = [&](int t) {
     const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
     n0e = tn * kBN;
-    const int m0 = tm * BM;
+    const int r0 = tm * BM + g * (R * 16) + (lane & 15);  // row of (a = 0, mi = 0); the others are 16 mi + HR a further
+    int img, rem;
+    divmod_f(r0 < p.M ? r0 : 0, P, p.rcpP, img, rem);
+    const unsigned out_img = (unsigned)p.OHp * p.OWp * (unsigned)p.N;
 #pragma unroll
     for (int i = 0; i < 2 * R; ++i) {
-      const int r = m0 + (i / R) * HR + g * (R * 16) + (i % R) * 16 + (lane & 15);
-      int img, rem, oh, ow;
-      divmod_f(r < p.M ? r : 0, P, p.rcpP, img, rem);
-      divmod_f(rem, p.OW, p.rcpOW, oh, ow);
-      const unsigned pix = ((unsigned)img * p.OHp + oh + p.ob) * p.OWp + ow + p.ob;
-      obase[i] = r < p.M ? pix * (unsigned)p.N : kRowInvalid;
+      const int r = r0 + (i / R) * HR + (i % R) * 16;
+      obase[i] = r < p.M ? (unsigned)img * out_img + reinterpret_cast<const unsigned*>(smem + kTabOff + 4 * kMaxP)[rem] : kRowInvalid;
+      rem += (i % R == R - 1) ? HR - (R - 1) * 16 : 16;  // on to the next row
+      while (rem >= P) {
+        rem -= P;
+        ++img;
+      }
     }
   };
   // this lane's 8 bytes of a 32-feature row piece after the swap below: features 16 (q & 1) + 8 (q >> 1) ...
@@ -356,15 +372,26 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
   //   phase 1: stores (1,0) of the previous tile | A1(t+1)        phase 3: stores (0,1) | A0(t+2)
   //   phase 2: stores (0,0)                      | B0(t+2)        phase 4: stores (1,1) | B1(t+2)
   // Waits (each in the phase before the read, behind that phase's own DMA), = 10 + R x (store groups in between):
+  //   (the phase's second piece follows its MFMAs, so 9 of the 10 are out when the wait executes)
   //   phase 1 for B1(t)   (issued phase 4 of t-2): + 4 R when t is a first K tile (3 of the previous tile's last
   //                        K tile, 1 of this phase), + R when t-1 was a first K tile with stores;
   //   phase 2 for A1(t)   (issued phase 1 of t-1): + 4 R when t is first, + R when t is last;
   //   phase 4 for A0(t+1), B0(t+1) (issued phases 3 / 2 of t-1): + 2 R when t is first, + 3 R when t is last.
   bool tile_has_prev = false;  // the current tile's first K tile stored quadrant (1,0) of a previous tile
+  // DBG bit 11: s_memtime stamps around the slots of phase 2 of every middle K tile (diagnostic build: the stamps'
+  // lgkmcnt(0) forbids overlaps the real kernel has; read shares, not lengths)
+  unsigned long long sl[7] = {0, 0, 0, 0, 0, 0, 0}, sn = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0, tg = 0, th = 0;
+  auto stamp = [&](unsigned long long& t) {
+    if (DBG & 2048) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  };
   auto ktile = [&](bool first, bool second, bool last) {
     const int os = cs ^ kStage;
     const bool fp = first && tile_has_prev;
     // ---- phase 1: quadrant (0, 0)
+    if ((DBG & 1024) && !(DBG & 2)) {
+      fill_A(os, 1, aA1, koff1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     read_A(I0{}, I0{});
     read_A(I0{}, I1{});
     read_B(I0{});
@@ -374,11 +401,11 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     if (!(DBG & 2)) {
-      fill_A(os, 1, aA1, koff1);
+      if (!(DBG & 1024)) fill_A(os, 1, aA1, koff1, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (fp) pp_wait_vm<10 + 4 * R>();
-      else if (second && tile_has_prev) pp_wait_vm<10 + R>();
-      else pp_wait_vm<10>();
+      if (fp) pp_wait_vm<9 + 4 * R, DBG>();
+      else if (second && tile_has_prev) pp_wait_vm<9 + R, DBG>();
+      else pp_wait_vm<9, DBG>();
     }
     __builtin_amdgcn_sched_barrier(0);
     xor_frag(0);
@@ -386,8 +413,14 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     PP_BAR();
     mfma_quad(I0{}, I0{}, std::true_type{});
+    if (!(DBG & 2)) fill_A(os, 1, aA1, koff1, 1);
     PP_BAR();
     // ---- phase 2: quadrant (0, 1)
+    stamp(ta);
+    if ((DBG & 1024) && !(DBG & 2)) {
+      fill_B(r2, bB0, c2_kt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     read_B(I1{});
     if (first) {
       init_acc(I0{}, I1{});
@@ -395,46 +428,74 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
     }
     if (last) epilogue(I0{}, I0{});
     __builtin_amdgcn_sched_barrier(0);
+    stamp(tg);
     if (!(DBG & 2)) {
-      fill_B(r2, bB0, c2_kt);
+      if (!(DBG & 1024)) fill_B(r2, bB0, c2_kt, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (fp) pp_wait_vm<10 + 4 * R>();
-      else if (last) pp_wait_vm<10 + R>();
-      else pp_wait_vm<10>();
+      stamp(th);
+      if (fp) pp_wait_vm<9 + 4 * R, DBG>();
+      else if (last) pp_wait_vm<9 + R, DBG>();
+      else pp_wait_vm<9, DBG>();
     }
     __builtin_amdgcn_sched_barrier(0);
+    stamp(tb);
     PP_BAR();
+    stamp(tc);
     mfma_quad(I0{}, I1{}, std::false_type{});
+    stamp(td);
+    if (!(DBG & 2)) fill_B(r2, bB0, c2_kt, 1);
+    stamp(te);
     PP_BAR();
+    stamp(tf);
+    if ((DBG & 2048) && !first && !last) {
+      sl[0] += tb - ta;
+      sl[1] += tc - tb;
+      sl[2] += td - tc;
+      sl[3] += te - td;
+      sl[4] += tf - te;
+      sl[5] += th - tg;  // the load slot's DMA piece
+      sl[6] += tb - th;  // the counted vmcnt wait
+      ++sn;
+    }
     // ---- phase 3: quadrant (1, 1)
+    if ((DBG & 1024) && !(DBG & 2)) {
+      fill_A(cs, 0, aA0, koff2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     read_A(I1{}, I0{});
     read_A(I1{}, I1{});
     if (first) init_acc(I1{}, I1{});
     if (last) epilogue(I0{}, I1{});
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DBG & 2)) fill_A(cs, 0, aA0, koff2);
+    if (!(DBG & 2) && !(DBG & 1024)) fill_A(cs, 0, aA0, koff2, 0);
     __builtin_amdgcn_sched_barrier(0);
     xor_frag(0);
     xor_frag(1);
     __builtin_amdgcn_sched_barrier(0);
     PP_BAR();
     mfma_quad(I1{}, I1{}, std::true_type{});
+    if (!(DBG & 2)) fill_A(cs, 0, aA0, koff2, 1);
     PP_BAR();
     // ---- phase 4: quadrant (1, 0)
+    if ((DBG & 1024) && !(DBG & 2)) {
+      fill_B(cs + 3 * kHalf, bB1, c2_kt, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     read_B(I0{});
     if (first) init_acc(I1{}, I0{});
     if (last) epilogue(I1{}, I1{});
     __builtin_amdgcn_sched_barrier(0);
     if (!(DBG & 2)) {
-      fill_B(cs + 3 * kHalf, bB1, c2_kt);
+      if (!(DBG & 1024)) fill_B(cs + 3 * kHalf, bB1, c2_kt, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (fp) pp_wait_vm<10 + 2 * R>();
-      else if (last) pp_wait_vm<10 + 3 * R>();
-      else pp_wait_vm<10>();
+      if (fp) pp_wait_vm<9 + 2 * R, DBG>();
+      else if (last) pp_wait_vm<9 + 3 * R, DBG>();
+      else pp_wait_vm<9, DBG>();
     }
     __builtin_amdgcn_sched_barrier(0);
     PP_BAR();
     mfma_quad(I1{}, I0{}, std::false_type{});
+    if (!(DBG & 2)) fill_B(cs + 3 * kHalf, bB1, c2_kt, 1);
     PP_BAR();
     // ---- both cursors move on by one K tile; the stages swap, the B0 ring turns
     koff1 = koff2;
@@ -453,25 +514,30 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
   };
 
   // ---- prologue: K tile 0 of the first tile into stage 0, B0 / A0 / B1 of K tile 1 into stage 1
+  __syncthreads();  // the row tables (and oc') are in LDS
   {
     c1_rows();
     c2_rows();
     const unsigned k0 = koff_of(0);
-    fill_A(0, 0, aA0, k0);
-    fill_A(0, 1, aA1, k0);
-    fill_B(r0, bB0, 0);
-    fill_B(3 * kHalf, bB1, 0);
+    for (int j = 0; j < 2; ++j) {
+      fill_A(0, 0, aA0, k0, j);
+      fill_A(0, 1, aA1, k0, j);
+      fill_B(r0, bB0, 0, j);
+      fill_B(3 * kHalf, bB1, 0, j);
+    }
     next_kt(c2_tile, c2_kt);  // K tile 1 (nk >= 2: same tile)
     koff1 = koff_of(1);
-    fill_B(r1, bB0, 1);
-    fill_A(kStage, 0, aA0, koff1);
-    fill_B(kStage + 3 * kHalf, bB1, 1);
+    for (int j = 0; j < 2; ++j) {
+      fill_B(r1, bB0, 1, j);
+      fill_A(kStage, 0, aA0, koff1, j);
+      fill_B(kStage + 3 * kHalf, bB1, 1, j);
+    }
     next_kt(c1_tile, c1_kt);  // cursor 1 = K tile 1
     if (next_kt(c2_tile, c2_kt)) c2_rows();  // cursor 2 = K tile 2 (of the next tile when nk == 2)
     koff2 = koff_of(c2_kt);
   }
   PP_WAIT_VM(0);
-  __syncthreads();  // (also publishes the oc' table)
+  __syncthreads();
   if (g == 1 && !(DBG & 256)) PP_BAR();  // the second group runs one barrier behind the first
 
   unsigned long long st_c = 0, st_r = 0, st_k = 0;
@@ -492,6 +558,10 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
   if (g == 0 && !(DBG & 256)) PP_BAR();
   if (DBG & 8) {
     const unsigned long long e_c = __builtin_amdgcn_s_memtime(), e_r = __builtin_amdgcn_s_memrealtime();
+    if ((DBG & 2048) && lane == 0) {
+      for (int i = 0; i < 7; ++i) p.dbg[4096 * 4 + (blockIdx.x * 8 + wave) * 8 + i] = sl[i];
+      p.dbg[4096 * 4 + (blockIdx.x * 8 + wave) * 8 + 7] = sn;
+    }
     if (tid == 0) {
       p.dbg[blockIdx.x * 4 + 0] = e_c - st_c;
       p.dbg[blockIdx.x * 4 + 1] = e_r - st_r;
@@ -563,7 +633,7 @@ extern "C" int i8ie_requant_eval_host(float sa, float sb, float sc, int zp_c, in
 
 int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   if (c.amode != 1 || c.acc != nullptr || c.biasf != nullptr) return 0;
-  if (c.N % 16 != 0 || c.N <= 128 || c.N > kOcpMax || c.Npad > kOcpMax) return 0;
+  if (c.N % 16 != 0 || c.N <= 128 || c.N > kOcpMax || c.Npad > kOcpMax || c.OH * c.OW > kMaxP) return 0;
   if ((reinterpret_cast<uintptr_t>(c.out) & 15u) != 0 || c.C % 16 != 0) return 0;
   const int nk = c.Kpad / 128;
   if (nk < 2 || c.M >= (1 << 23) || c.M < 256 * 64) return 0;  // the tiled kernel serves small launches
@@ -612,6 +682,7 @@ int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   prop = &props[dev];
   int grid = prop->multiProcessorCount / 8 * 8;
   if (grid < 8) grid = 8;
+  if (const char* e = std::getenv("I8IE_PP_GRID")) grid = std::atoi(e) / 8 * 8 > 0 ? std::atoi(e) / 8 * 8 : grid;  // (experiments)
   const double ops = 2.0 * c.M * c.N * c.Ktrue;
   const double bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
   char tag[64];
@@ -621,9 +692,9 @@ int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   // variants 21-23 / 24-27: diagnostic builds (see DBG above); 24-27 print the in-kernel clock to stderr
   static unsigned long long* dbg_dev = nullptr;
   const int v = ctx->variant;
-  if (v >= 24 && v <= 27) {
-    if (dbg_dev == nullptr) I8IE_HIP_TRY(hipMalloc((void**)&dbg_dev, 4096 * 4 * sizeof(unsigned long long)));
-    I8IE_HIP_TRY(hipMemsetAsync(dbg_dev, 0, 4096 * 4 * sizeof(unsigned long long), ctx->stream));
+  if ((v >= 24 && v <= 27) || v == 38 || v == 39) {
+    if (dbg_dev == nullptr) I8IE_HIP_TRY(hipMalloc((void**)&dbg_dev, (4096 * 4 + 4096 * 8 * 8) * sizeof(unsigned long long)));
+    I8IE_HIP_TRY(hipMemsetAsync(dbg_dev, 0, (4096 * 4 + 4096 * 8 * 8) * sizeof(unsigned long long), ctx->stream));
     a.dbg = dbg_dev;
   }
   if (v == 21) rc = launch_pp<R, true, 1>(ctx, a, grid);
@@ -634,13 +705,34 @@ int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   else if (v == 32) rc = launch_pp<R, true, 1 | 64>(ctx, a, grid);
   else if (v == 33) rc = launch_pp<R, true, 1 | 128>(ctx, a, grid);
   else if (v == 34) rc = launch_pp<R, true, 1 | 4>(ctx, a, grid);
+  else if (v == 37) rc = launch_pp<R, true, 1 | 1024>(ctx, a, grid);
+  else if (v == 40) rc = launch_pp<R, true, 1 | 4096>(ctx, a, grid);
   else if (v == 35) rc = launch_pp<R, true, 1 | 256>(ctx, a, grid);
   else if (v == 36) rc = launch_pp<R, true, 1 | 512>(ctx, a, grid);
+  else if (v == 38) rc = launch_pp<R, true, 8 | 2048 | 1>(ctx, a, grid);
+  else if (v == 39) rc = launch_pp<R, true, 8 | 2048 | 1 | 2>(ctx, a, grid);
   else if (v == 24) rc = launch_pp<R, true, 8>(ctx, a, grid);
   else if (v == 25) rc = launch_pp<R, true, 9>(ctx, a, grid);
   else if (v == 26) rc = launch_pp<R, true, 11>(ctx, a, grid);
   else if (v == 27) rc = launch_pp<R, true, 15>(ctx, a, grid);
   else rc = proven ? launch_pp<R, true>(ctx, a, grid) : launch_pp<R, false>(ctx, a, grid);
+  if (rc == I8IE_OK && (v == 38 || v == 39) && std::getenv("I8IE_PP_CLOCK") != nullptr) {
+    std::vector<unsigned long long> h((size_t)grid * 8 * 8);
+    I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    I8IE_HIP_TRY(hipMemcpy(h.data(), dbg_dev + 4096 * 4, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double s[2][7] = {}, n[2] = {};
+    for (int b = 0; b < grid; ++b)
+      for (int w = 0; w < 8; ++w) {
+        const unsigned long long* e = &h[((size_t)b * 8 + w) * 8];
+        if (e[7] == 0) continue;
+        for (int i = 0; i < 7; ++i) s[w >> 2][i] += (double)e[i] / (double)e[7];
+        n[w >> 2] += 1;
+      }
+    for (int gi = 0; gi < 2; ++gi)
+      if (n[gi] > 0)
+        fprintf(stderr, "pp_stamps variant %d group %d phase 2 (cycles): load slot %.0f | barrier %.0f | 16 MFMA %.0f | tail DMA %.0f | barrier %.0f ; inside the load slot: DMA piece %.0f, vmcnt wait %.0f\n", v,
+                gi, s[gi][0] / n[gi], s[gi][1] / n[gi], s[gi][2] / n[gi], s[gi][3] / n[gi], s[gi][4] / n[gi], s[gi][5] / n[gi], s[gi][6] / n[gi]);
+  }
   if (rc == I8IE_OK && v >= 24 && v <= 27 && std::getenv("I8IE_PP_CLOCK") != nullptr) {
     std::vector<unsigned long long> h((size_t)grid * 4);
     I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -60,9 +60,14 @@ def test_pp_conv_bit_exact(gpu, orc, geom, relu, ob):
     cs = synth.conv_case(orc, 1234 + sum(geom), n, c, h, w, kc, k, stride, pad)
 
     def run():
-        return gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
-                                       cs["s_out"], cs["zp_out"], stride=stride, pad=pad, in_nhwc=True,
-                                       out_nhwc=True, relu=relu, in_border=pad, out_border=ob, want_acc=False)
+        lib = abi.lib()
+        abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 20))  # the pp kernel is an opt-in variant
+        try:
+            return gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
+                                           cs["s_out"], cs["zp_out"], stride=stride, pad=pad, in_nhwc=True,
+                                           out_nhwc=True, relu=relu, in_border=pad, out_border=ob, want_acc=False)
+        finally:
+            abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
 
     (out, _, _), names = _kernels_run(gpu, run)  # (the harness also checks that border bytes stay zp_out)
     assert any(nm.startswith("pp_conv") for nm in names), names
@@ -82,11 +87,11 @@ def test_pp_conv_matches_tiled_kernel_on_extreme_operands(gpu, orc):
     want = orc.conv2d(q_in, qw, qb, 1, 1, np.float32(s_in), zp_in, np.float32(s_w), np.float32(s_out), zp_out)[0]
     lib = abi.lib()
     outs = {}
-    for variant in (0, 11):
+    for variant in (20, 11):
         abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, variant))
         try:
             outs[variant] = gpu.layer_forward_fused("conv", q_in, qw, qb, s_in, zp_in, s_w, s_out, zp_out, stride=1,
                                                     pad=1, in_nhwc=True, out_nhwc=True, in_border=1, want_acc=False)[0]
         finally:
             abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
-    assert np.array_equal(outs[0], want) and np.array_equal(outs[11], want)
+    assert np.array_equal(outs[20], want) and np.array_equal(outs[11], want)

@@ -47,6 +47,44 @@ __global__ __launch_bounds__(1024) void probe(const unsigned char* src, size_t w
   if (keep.x == 0x12345678) sink[0] = keep.y + keep.z + keep.w;
 }
 
+// MFMA waves beside DMA waves: waves [0, nd) issue LDS-DMA bursts, waves [nd, nw) run back-to-back 16x16x64 int8
+// MFMAs from registers.  Reports the DMA rate and the MFMA rate when both run together.
+__global__ __launch_bounds__(1024) void mixed(const unsigned char* src, size_t window, int rounds, int pieces, int nd,
+                                              int mfma_per_round, unsigned long long* out, int* sink, int pitch = 128) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned char* base = src + (size_t)blockIdx.x * window;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, (unsigned)window, 0x00020000);
+  v4i a = {tid * 7, tid * 13, tid ^ 0x55, tid * 0x01010101}, b = {tid * 3, tid * 17, tid ^ 0x33, tid * 0x01030107};
+  v4i c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (wave < nd) {
+    // a piece = 8 rows x 128 B at `pitch` (128: one contiguous KiB)
+    unsigned off = (unsigned)(wave * 8 * pitch + (lane >> 3) * pitch + (lane & 7) * 16);
+    for (int r = 0; r < rounds; ++r) {
+      for (int i = 0; i < pieces; ++i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + wave * 8192 + (i & 7) * 1024), 16,
+                                                 (int)(off & (unsigned)(window - 1)), 0, 0, 0);
+        off += (unsigned)(nd * 8 * pitch);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else {
+    for (int r = 0; r < rounds; ++r)
+      for (int i = 0; i < mfma_per_round; i += 4) {
+        c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(b, b, c3, 0, 0, 0);
+      }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) out[blockIdx.x * 16 + wave] = t1 - t0;
+  if ((c0.x ^ c1.y ^ c2.z ^ c3.w) == 0x12345678) sink[0] = 1;
+}
+
 int main() {
   const int CUS = 256;
   unsigned char* src;
@@ -64,7 +102,7 @@ int main() {
   hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192);
-  for (int mode = 0; mode < 3; ++mode)
+  for (int mode = 0; mode < 0; ++mode)
     for (size_t window : {(size_t)65536, (size_t)4 << 20})
       for (int waves : {1, 4, 8, 12})
         for (int pieces : {2, 8, 32}) {
@@ -89,5 +127,26 @@ int main() {
           printf("%-16s window %7zu KiB  waves/CU %2d  burst %2d: %7.1f cycles per piece per wave, %6.1f B/clk/CU\n", names[mode],
                  window >> 10, waves, pieces, per_piece, 1024.0 * waves / per_piece);
         }
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&mixed), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8192);
+  for (int pitch : {128, 384, 3456})
+   for (int nd : {4, 8})
+    for (int nm : {0, 4})
+      for (int pieces : {2, 8}) {
+        const int rounds = 1024 / pieces, mpr = pieces * 16;  // MFMA waves: 16 MFMAs (256 cycles) per DMA piece of the others
+        const int waves = nd + nm;
+        for (int rep = 0; rep < 2; ++rep) mixed<<<CUS, waves * 64, 16 * 8192, 0>>>(src, (size_t)65536, rounds, pieces, nd, mpr, out, sink, pitch);
+        hipDeviceSynchronize();
+        hipMemcpy(h.data(), out, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sd = 0, sm = 0;
+        for (int b = 0; b < CUS; ++b) {
+          for (int w = 0; w < nd; ++w) sd += (double)h[b * 16 + w];
+          for (int w = nd; w < waves; ++w) sm += (double)h[b * 16 + w];
+        }
+        const double dcyc = sd / (CUS * nd) / (rounds * pieces);
+        printf("mixed pitch %4d: %d DMA waves + %d MFMA waves per CU, burst %d: %6.1f cycles per piece per DMA wave (%5.1f B/clk/CU)", pitch, nd, nm, pieces,
+               dcyc, 1024.0 * nd / dcyc);
+        if (nm) printf(", MFMA waves %5.1f cycles per MFMA", sm / (CUS * nm) / ((double)rounds * mpr));
+        printf("\n");
+      }
   return 0;
 }
