@@ -137,6 +137,12 @@ int i8ie_relu_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int64_t
 /* max_pool2d<u8_t>  src/functional.cc:36-64: NCHW, k x k window, stride s, floor, no padding */
 int i8ie_maxpool2d_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int n, int c,
                       int h, int w, int kernel_size, int stride);
+/* the s8 instantiations the reference registers as well (src/functional.cc:78-82): the generic templates,
+ * relu = x > 0 ? x : 0 (src/functional.cc:5-13), max-pool with a running maximum starting at -127
+ * (src/functional.cc:28-31, 36-64).  NCHW, no quantisation parameters involved. */
+int i8ie_relu_s8(i8ie_ctx* ctx, const int8_t* in_dev, int8_t* out_dev, int64_t n);
+int i8ie_maxpool2d_s8(i8ie_ctx* ctx, const int8_t* in_dev, int8_t* out_dev, int n, int c, int h, int w,
+                      int kernel_size, int stride);
 /* down_scale  src/quantize_utils.cc:27-36 (standalone requantiser; the layers fuse it) */
 int i8ie_down_scale(i8ie_ctx* ctx, const int32_t* acc_dev, uint8_t* out_dev, int64_t n, float sa,
                     float sb, float sc, uint8_t zp_c);

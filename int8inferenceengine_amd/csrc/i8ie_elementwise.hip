@@ -120,6 +120,34 @@ __global__ __launch_bounds__(kThreads) void maxpool_u8_nchw_kernel(const uint8_t
   }
 }
 
+// ---- the s8 instantiations the reference also registers (src/functional.cc:78-82): the generic templates,
+// relu = x > 0 ? x : 0 (src/functional.cc:5-13), max-pool with a running maximum that starts at
+// -numeric_limits<char>::max() = -127 (src/functional.cc:28-31).  Nothing on the INT8 inference path produces
+// an s8 tensor; they exist so that the drop-in module offers every overload the reference does.
+__global__ __launch_bounds__(kThreads) void relu_s8_kernel(const int8_t* in, int8_t* out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) out[i] = in[i] > 0 ? in[i] : (int8_t)0;
+}
+__global__ __launch_bounds__(kThreads) void maxpool_s8_nchw_kernel(const int8_t* __restrict__ in, int8_t* __restrict__ out,
+                                                                   int64_t total, int h, int w, int oh, int ow, int k,
+                                                                   int s) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += stride) {
+    const int x = (int)(e % ow);
+    const int64_t t = e / ow;
+    const int y = (int)(t % oh);
+    const int64_t plane = t / oh;
+    const int8_t* p = in + plane * h * w + (int64_t)(y * s) * w + x * s;
+    int mx = -127;
+    for (int m = 0; m < k; ++m)
+      for (int l = 0; l < k; ++l) {
+        const int v = p[m * w + l];
+        mx = mx >= v ? mx : v;
+      }
+    out[e] = (int8_t)mx;
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -189,6 +217,31 @@ int i8ie_maxpool2d_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int
   I8ieProfScope prof(ctx, "maxpool_u8_nchw", 0.0, (double)n * c * h * w + (double)total);
   maxpool_u8_nchw_kernel<<<grid_for(total), kThreads, 0, ctx->stream>>>(in, out, total, h, w, oh, ow,
                                                                        k, s);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+int i8ie_relu_s8(i8ie_ctx* ctx, const int8_t* in, int8_t* out, int64_t n) {
+  I8IE_REQUIRE(ctx && in && out, "null argument");
+  I8IE_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return I8IE_OK;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8ieProfScope prof(ctx, "relu_s8", 0.0, 2.0 * n);
+  relu_s8_kernel<<<grid_for(n), kThreads, 0, ctx->stream>>>(in, out, n);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+int i8ie_maxpool2d_s8(i8ie_ctx* ctx, const int8_t* in, int8_t* out, int n, int c, int h, int w, int k, int s) {
+  I8IE_REQUIRE(ctx && in && out, "null argument");
+  I8IE_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, "non-positive dimension");
+  I8IE_REQUIRE(k > 0 && s > 0, "kernel_size and stride must be positive");
+  I8IE_REQUIRE(k <= h && k <= w, "window larger than the input");
+  const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
+  const int64_t total = (int64_t)n * c * oh * ow;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8ieProfScope prof(ctx, "maxpool_s8_nchw", 0.0, (double)n * c * h * w + (double)total);
+  maxpool_s8_nchw_kernel<<<grid_for(total), kThreads, 0, ctx->stream>>>(in, out, total, h, w, oh, ow, k, s);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }

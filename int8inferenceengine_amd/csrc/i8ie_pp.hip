@@ -193,6 +193,19 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + lds_off), 16,
                                              (int)voff, soff, 0, 0);
   };
+  // weights: every CU streams the same panel once per tile and never re-reads a line, so they go around the L1
+  // (sc1: served by L2 as usual) and leave it to the activation windows, whose K tiles overlap
+  auto dma_b = [&](const __amdgpu_buffer_rsrc_t& rs, int lds_off, unsigned voff, int soff) {
+    if (DBG & 8192)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + lds_off), 16,
+                                               (int)voff, soff, 0, 16);
+    else if (DBG & 16384)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + lds_off), 16,
+                                               (int)voff, soff, 0, 2);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + lds_off), 16,
+                                               (int)voff, soff, 0, 0);
+  };
   // half-tile `hb` (0 A0, 1 A1, 2 B0, 3 B1) of stage `st`: this wave's two pieces
   // piece j (0 / 1) of a half-tile: the first one goes out in the load slot, the second behind the phase's last
   // MFMA (an LDS-DMA instruction holds its wave for ~150 cycles while the SIMD's other wave issues MFMAs, ~70
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
   };
   auto fill_B = [&](int buf, const unsigned (&off)[2], int kt, int j) {  // buf: LDS offset of the half-tile buffer
     if (DBG & 64) return;
-    dma(rsB, buf + (j * 64 + wave * 8) * 128, (DBG & 128) ? (off[j] & 0xFFFFu) : off[j], (DBG & 128) ? 0 : kt * 128);
+    dma_b(rsB, buf + (j * 64 + wave * 8) * 128, (DBG & 128) ? (off[j] & 0xFFFFu) : off[j], (DBG & 128) ? 0 : kt * 128);
   };
   unsigned aA1[2], koff1;                   // cursor 1 = K tile t + 1 (A1)
   unsigned aA0[2], bB0[2], bB1[2], koff2;   // cursor 2 = K tile t + 2 (B0, A0, B1)
@@ -707,6 +720,8 @@ int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   else if (v == 34) rc = launch_pp<R, true, 1 | 4>(ctx, a, grid);
   else if (v == 37) rc = launch_pp<R, true, 1 | 1024>(ctx, a, grid);
   else if (v == 40) rc = launch_pp<R, true, 1 | 4096>(ctx, a, grid);
+  else if (v == 41) rc = launch_pp<R, true, 1 | 8192>(ctx, a, grid);
+  else if (v == 42) rc = launch_pp<R, true, 1 | 16384>(ctx, a, grid);
   else if (v == 35) rc = launch_pp<R, true, 1 | 256>(ctx, a, grid);
   else if (v == 36) rc = launch_pp<R, true, 1 | 512>(ctx, a, grid);
   else if (v == 38) rc = launch_pp<R, true, 8 | 2048 | 1>(ctx, a, grid);

@@ -270,6 +270,37 @@ std::shared_ptr<Storage> nhwc_storage(const std::vector<ssize_t>& shp, int b, in
   return s;
 }
 
+// A recorded (not yet launched) operation.  Every holder -- python-side copies of the tensor, relu(y) made from y,
+// the closures of consumers that captured their input -- shares ONE node, and the node remembers what it has
+// produced: a producer observed twice, or consumed by two ops, launches once per distinct (relu, border) request,
+// and its upstream chain (whose nodes cache in the same way) is never launched again.
+struct PendNode {
+  std::function<std::shared_ptr<Storage>(bool, int)> fn;
+  struct Made {
+    bool relu;
+    int border;
+    std::shared_ptr<Storage> st;
+  };
+  std::vector<Made> made;
+  std::shared_ptr<Storage> get(bool relu, int border) {
+    for (const Made& m : made)
+      if (m.relu == relu && m.border == border && m.st) {
+        // a bordered NHWC result that was since converted in place (to_nchw) no longer has the border asked for
+        if (border > 0 && (m.st->layout != I8IE_LAYOUT_NHWC || m.st->border != border)) continue;
+        return m.st;
+      }
+    std::shared_ptr<Storage> st = fn(relu, border);
+    made.push_back(Made{relu, border, st});
+    return st;
+  }
+};
+template <typename F>
+std::shared_ptr<PendNode> make_pend(F&& f) {
+  auto n = std::make_shared<PendNode>();
+  n->fn = std::forward<F>(f);
+  return n;
+}
+
 // ----------------------------------------------------------------- tensor ----
 template <typename T>
 struct Tensor {
@@ -281,7 +312,7 @@ struct Tensor {
   // A layer forward that has been recorded but not launched yet: lets a following relu
   // fold into the epilogue.  Launching is observationally identical to the eager call.
   // arguments: fuse relu; physical border wanted by the consumer (honoured for NHWC results)
-  std::shared_ptr<std::function<std::shared_ptr<Storage>(bool, int)>> pend;
+  std::shared_ptr<PendNode> pend;
   bool pend_relu = false;
   // a pending small Linear layer can also produce dequantize(layer(x)) directly (argument: fuse relu)
   std::shared_ptr<std::function<std::shared_ptr<Storage>(bool)>> pend_f32;
@@ -292,7 +323,7 @@ struct Tensor {
 
   void realize(int border = 0) {
     if (!pend) return;
-    st = (*pend)(pend_relu, border);
+    st = pend->get(pend_relu, border);
     pend.reset();
     pend_f32.reset();
     qsrc.reset();
@@ -553,7 +584,7 @@ Tensor<u8_t> quantize(Tensor<float>& in, float scale, u8_t zp) {  // src/quantiz
   out.qscale = scale;
   out.qzp = zp;
   // deferred: a first conv layer that accepts FP32 input consumes `src` directly (fused quantize)
-  out.pend = std::make_shared<std::function<std::shared_ptr<Storage>(bool, int)>>(
+  out.pend = make_pend(
       [src, n, scale, zp](bool relu, int) {
         auto st = device_storage((size_t)n);
         check(i8ie_quantize_f32_u8(ctx(), (const float*)src->device_ptr(), (uint8_t*)st->dev, n, scale, zp));
@@ -623,7 +654,7 @@ Tensor<u8_t> max_pool2d_u8(Tensor<u8_t>& in, ssize_t k, ssize_t s) {  // src/fun
   const u8_t zp = in.zero_point;
   const int kk = (int)k, ss = (int)s;
   // deferred so that a consuming conv can ask for a zero-point border around the result
-  out.pend = std::make_shared<std::function<std::shared_ptr<Storage>(bool, int)>>(
+  out.pend = make_pend(
       [src, ishp, oshp, zp, kk, ss](bool relu, int border) mutable {
         const uint8_t* ip = src.dptr_any();
         std::shared_ptr<Storage> st;
@@ -640,6 +671,21 @@ Tensor<u8_t> max_pool2d_u8(Tensor<u8_t>& in, ssize_t k, ssize_t s) {  // src/fun
         if (relu) check(i8ie_relu_u8(ctx(), (const uint8_t*)st->dev, (uint8_t*)st->dev, (int64_t)st->bytes, zp));
         return st;
       });
+  return out;
+}
+// the s8 instantiations of the generic templates (src/functional.cc:5-13, 36-64, registered at :78-82)
+Tensor<s8_t> relu_s8(Tensor<s8_t>& in) {
+  if (!in.st) return Tensor<s8_t>();  // default-constructed: nothing to do
+  Tensor<s8_t> out(in.shape);  // (the generic relu does not carry scale / zero point over: src/functional.cc:7)
+  if (in.size > 0) check(i8ie_relu_s8(ctx(), (const int8_t*)in.dptr(), (int8_t*)out.dptr(), in.size));
+  return out;
+}
+Tensor<s8_t> max_pool2d_s8(Tensor<s8_t>& in, ssize_t k, ssize_t s) {
+  Tensor<s8_t> out(pool_shape(in, k, s));
+  out.scale = in.scale;  // src/functional.cc:43-44
+  out.zero_point = in.zero_point;
+  check(i8ie_maxpool2d_s8(ctx(), (const int8_t*)in.dptr(), (int8_t*)out.dptr(), (int)in.shape[0], (int)in.shape[1],
+                          (int)in.shape[2], (int)in.shape[3], (int)k, (int)s));
   return out;
 }
 Tensor<float> max_pool2d_f32(Tensor<float>& in, ssize_t k, ssize_t s) {
@@ -829,7 +875,7 @@ class BaseLayer {
     const int zp_out = zero_point_;
     const std::vector<ssize_t> oshp = out.shape;
     const size_t obytes = (size_t)out.size;
-    out.pend = std::make_shared<std::function<std::shared_ptr<Storage>(bool, int)>>(
+    out.pend = make_pend(
         [handle, src, s_in, zp_in, zp_out, m, h, w, spatial, oshp, obytes](bool relu, int border) mutable {
           int out_layout = I8IE_LAYOUT_NCHW, pad = 0;
           if (spatial) {
@@ -1087,12 +1133,26 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
 
   m.def("tensor", &tensor_from_numpy);  // src/pybind11.cc:38-40
   m.def("tensor_from_device", &tensor_from_device);
+  // additive (the reference can only default-construct its s8 tensors from Python): an s8 tensor from an ndarray,
+  // so that the s8 overloads of relu / max_pool2d can be exercised
+  m.def("tensor_s8", [](py::array_t<s8_t, py::array::c_style | py::array::forcecast> a, float scale, int zp) {
+    Tensor<s8_t> t(std::vector<ssize_t>(a.shape(), a.shape() + a.ndim()));
+    t.scale = scale;
+    t.zero_point = (u8_t)zp;
+    if (t.size > 0) {
+      py::gil_scoped_release nogil;
+      check(i8ie_memcpy_h2d(ctx(), t.dptr(), a.data(), (size_t)t.size));
+    }
+    return t;
+  }, py::arg("array"), py::arg("scale") = 1.0f, py::arg("zero_point") = 0);
   m.def("quantize", &quantize);         // src/pybind11.cc:41-45
   m.def("dequantize", &dequantize);     // src/pybind11.cc:46-48
   m.def("relu", &relu_f32);             // src/functional.cc:73-75
   m.def("relu", &relu_u8);
   m.def("max_pool2d", &max_pool2d_f32);  // src/functional.cc:68-72
   m.def("max_pool2d", &max_pool2d_u8);
+  m.def("relu", &relu_s8);               // src/functional.cc:81
+  m.def("max_pool2d", &max_pool2d_s8);
 
   {
     py::class_<Linear> c(m, "Linear");  // src/fully_connected.cc:54-72
