@@ -36,8 +36,8 @@ INT8_DENSE_PEAK_TOPS = 5000.0  # MI355X dense int8 MFMA: 2x the ~2.5 PF bf16 rat
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1000, help="global batch (images per step over all GPUs)")
     ap.add_argument("--network", default="alexnet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,52 +126,23 @@ def main():
     x_dev = i8ie.tensor(x_loc).prefetch()  # resident in HBM before the timed region
     cx.synchronize()
     h2d_ms = (time.perf_counter() - t_h2d0) * 1e3
-    if use_dist:
-        # logits of batch i wait here for the gather; two buffers so that batch i + 1 can be written meanwhile
-        stage = [torch.empty((stop - start, 10), dtype=torch.float32, device="cuda") for _ in range(2)]
-        side = torch.cuda.Stream()          # gather + read-back run here, beside the next batch's kernels
-        gathered = [None, None]             # event behind the last gather that read stage[k]
+    # N > 1: the package's runner owns the stage buffers, the side stream, the all-gather and rank 0's read-back
+    runner = sharding.ShardedRunner(net, n_total, 10, rank, world, host_copies=rehearse) if use_dist else None
 
     state = {"correct": 0, "logits": None}
-    if use_dist and rank == 0:
-        host_logits = [torch.empty((n_total, 10), dtype=torch.float32).pin_memory() for _ in range(2)]
-    tick = {"i": 0}
 
     def launch():
         """Queue one batch: quantize -> INT8 layers -> dequantize -> (gather) -> logits towards the host.
         Nothing here waits for the GPU."""
-        y = net(x_dev)
         if not use_dist:
-            return y.numpy_async()
-        k = tick["i"] & 1
-        tick["i"] += 1
-        main = torch.cuda.current_stream()
-        if gathered[k] is not None:
-            main.wait_event(gathered[k])   # the gather of two batches ago has finished reading stage[k]
-        cx.copy_to_ptr(y.data, stage[k].data_ptr())
-        ready = torch.cuda.Event()
-        ready.record(main)
-        with torch.cuda.stream(side):       # off the compute stream: the next batch does not wait for the collective
-            side.wait_event(ready)
-            full = gather(stage[k])         # RCCL all-gather of the per-shard logits
-            if rank == 0:
-                host_logits[k].copy_(full, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        gathered[k] = ev
-        if rank != 0:
-            return None
-        return host_logits[k], ev
+            return net(x_dev).numpy_async()
+        return runner.submit(x_dev)
 
     def consume(h):
         """Wait for one batch's logits, top-1 on the host (the reference's argmax + compare)."""
+        logits = runner.result(h) if use_dist else h.result()
         if rank != 0:
             return
-        if use_dist:
-            h[1].synchronize()
-            logits = h[0].numpy().copy()
-        else:
-            logits = h.result()
         pred = sharding.centred_argmax(logits, centre)
         state["correct"] = int((pred == lab_all).sum())
         state["logits"] = logits
@@ -200,7 +171,7 @@ def main():
     # untimed pre-warm: a second of steps so that clocks, allocator and caches are in steady state
     # before the contract's W warm-up steps (a fresh box measures its first ~20 steps 3-5 % slow)
     # (same count on every rank -- the steps contain a collective)
-    prewarm = 0 if os.environ.get("I8IE_BENCH_NO_PREWARM") else max(20, min(400, int(0.8 / (sharding.max_shard(n_total, world) * 2.1e-6 + 1.5e-4))))
+    prewarm = 0 if os.environ.get("I8IE_BENCH_NO_PREWARM") else max(10, min(150, int(0.25 / (sharding.max_shard(n_total, world) * 2.1e-6 + 1.5e-4))))
     run_steps(prewarm, pipelined)
     run_steps(args.warmup, pipelined)
     barrier()
@@ -292,28 +263,36 @@ def main():
     dom = max(mfma, key=lambda k: mfma[k]["ms"])
     d = timed.get(dom, mfma[dom])
     achieved = d["ops"] / (d["ms"] * 1e-3) / 1e12
-    traffic, traffic_src = None, None
-    try:  # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE), collected offline
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if tj.get("kernel") == dom and n_total == 1000 and world == 1:
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
-    except (OSError, ValueError, KeyError):
-        pass
+    # HBM bytes per launch of the dominant kernel: rocprofv3 PMC passes are collected offline (counter collection
+    # serialises every dispatch) and committed with the commit they were taken at; used only when they describe
+    # this kernel at this workload, otherwise null
+    traffic, traffic_meta = None, None
+    for cand in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            if tj.get("kernel") == dom and n_total == 1000 and world == 1 and name == "alexnet":
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_meta = {"file": "profiles/" + cand, "source": tj.get("source"), "collected_at_commit": tj.get("commit"),
+                                "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_launch")}
+                break
+        except (OSError, ValueError, KeyError):
+            pass
     roofline = {
         "bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": INT8_DENSE_PEAK_TOPS,
-        "unit": "TFLOP/s", "frac": round(achieved / INT8_DENSE_PEAK_TOPS, 4), "traffic": traffic,
-        "traffic_source": traffic_src,
+        "unit": "TOP/s", "frac": round(achieved / INT8_DENSE_PEAK_TOPS, 4), "traffic": traffic,
+        "traffic_provenance": traffic_meta,
         "ops_per_launch": d["ops"] / d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
         "launches_per_step": mfma[dom]["launches"] / args.steps,
         "launches_timed": d["launches"], "timed_in": "the timed region (every 5th contraction launch bracketed)" if prof else "untimed pass",
         "avg_launch_ms_untimed_pass_all_launches": round(mfma[dom]["ms"] / mfma[dom]["launches"], 4),
-        # context, not the contract's peak: what register-only int8 MFMA sustains on this chip when the operands
-        # toggle (tools/mfma_peak.hip k4; constant operands reach 4400-4900): profiles/r01h_mfma_peak_and_power.txt
-        "sustained_mfma_only_tops": {"random_operands": 3400.0, "constant_operands": 4860.0},
-        # rocm-smi while this kernel runs (profiles/r01j_clock_probe.txt): power-capped on toggling operands
-        "sclk_mhz_under_this_kernel": {"random_operands": 1912, "constant_operands": 2400, "nominal": 2400},
-        "package_power_w_under_this_kernel": {"random_operands": 1370, "constant_operands": 1192},
-        "frac_of_sustained_random_operand_rate": round(achieved / 3400.0, 4),
+    }
+    # NOT measured by this run: constants from committed profiles, kept apart from the measured fields above
+    static_context = {
+        "note": "constants from earlier measurements on MI355X, for reading `roofline`; nothing here is measured by this run",
+        "register_only_int8_mfma_tops": {"random_operands": 3400.0, "constant_operands": 4860.0,
+                                         "source": "profiles/r01h_mfma_peak_and_power.txt (tools/mfma_peak.hip)"},
+        "in_kernel_clock_mhz_contraction_kernels_random_operands": {"range": [1880, 2220], "nominal": 2400,
+                                                                    "source": "profiles/r02_inkernel_clock.txt (s_memtime / s_memrealtime stamps, csrc/i8ie_pp.hip diagnostic builds)"},
     }
     total_dev_ms = sum(v["ms"] for v in kernels.values())
     breakdown = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
@@ -396,13 +375,14 @@ def main():
                   "top1_delta": round(abs(t_gpu - t_cpu), 6), "images_compared": sample}
 
     out = {
-        "metric": "images/sec AlexNet-INT8 224x224 bs=1000", "value": round(value, 1), "unit": "images/sec",
+        "metric": "images/sec %s-INT8 %dx%d bs=%d" % (("AlexNet" if name == "alexnet" else name,) + wl.NETWORKS[name][2][1:] + (n_total,)),
+        "value": round(value, 1), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
         "config": {"workload": "%s INT8 forward + top-1, %dx%dx%d input, global batch %d sharded over %d GPU(s)"
                    % ((name,) + wl.NETWORKS[name][2] + (n_total, world)),
                    "global_batch": n_total, "per_gpu_batch": stop - start, "parallelism": "batch-shard x%d + logits all-gather" % world},
-        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "whole_step": whole,
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "whole_step": whole, "static_context": static_context,
         "kernel_ms_per_step": breakdown, "per_launch_shape": per_layer, "top1_vs_fp32_teacher": round(state["correct"] / n_total, 4),
         "prewarm_steps_untimed": prewarm,
         **({"REHEARSAL": "all ranks on one GPU, gloo collectives on host copies: control flow only, not a measurement"}

@@ -12,11 +12,13 @@
 //     16-byte K chunk (16 channels of one tap).  Rows past M and the K tail read
 //     whatever is there (or 0 past the end of the buffer): their B columns are zero /
 //     their outputs are never stored.
-//   * BK = 128 bytes per stage, 8 lanes per 128-byte line; two LDS stages, ONE barrier
-//     per K tile; LDS rows padded to 144 B: ds_read_b128 fragment reads are
-//     conflict-free (144/16 = 9 is odd) and the k-step offset is an immediate.
-//   * u8 -> s8 re-bias (x ^ 0x80) on the way into LDS; 128 * sum_k W joins oc[j] in the
-//     accumulator's initial value, so the accumulator is the reference's C bit for bit.
+//   * BK = 128 bytes per stage.  Convolutions (the default, VAR 5): ONE LDS stage filled by LDS-DMA
+//     (buffer_load ... lds, 1 KiB per wave-instruction) into unpadded 128-byte rows whose 16-byte chunk c of row r
+//     sits at c ^ (r & 7) (conflict-free ds_read_b128 fragments); fill -> vmcnt(0) + barrier -> compute ->
+//     barrier, three to four blocks per CU hide each other's fills.  Linear: register staging into 144-byte rows.
+//   * u8 -> s8 re-bias (x ^ 0x80) on the A fragments after the LDS read (DMA) or on the way into LDS (register
+//     staging); 128 * sum_k W joins oc[j] (ocp), which is added to the zero-initialised accumulators in the
+//     epilogue (integer adds commute exactly), so acc + ocp is the reference's C bit for bit.
 //   * MFMA operands swapped (weights are the row operand): the lane holds one
 //     activation row and 4 consecutive registers hold 4 consecutive output features,
 //     so the row-major (= NHWC) epilogue packs 4 u8 per lane.
@@ -910,7 +912,8 @@ int launch_cfg(i8ie_ctx* ctx, const IgemmArgs& a, const char* name, int kbytes, 
   I8ieProfScope prof(ctx, ctx->prof ? tag : name, ops, bytes);
   constexpr unsigned dyn_lds = VAR == 7 ? 2u * 65536u : 0u;
   if (VAR == 7) {
-    static bool raised = false;  // per instantiation: allow 128 KiB of dynamic LDS
+    static bool raised_on[64] = {};  // per instantiation and device: allow 128 KiB of dynamic LDS
+    bool& raised = raised_on[ctx->device & 63];
     if (!raised) {
       I8IE_HIP_TRY(hipFuncSetAttribute(
           reinterpret_cast<const void*>(&igemm_u8s8_kernel<AMODE, WM, WN, TM, TN, BIAS, ACC, VAR>),

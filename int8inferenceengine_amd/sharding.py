@@ -57,3 +57,106 @@ def centred_argmax(logits, centre):
     """Top-1 on random-init weights: subtract a fixed per-class centre first, otherwise every
     image lands in the same class and agreement is vacuous."""
     return np.argmax(np.asarray(logits, np.float32) - np.asarray(centre, np.float32)[None, :], axis=1)
+
+
+class ShardedRunner:
+    """The N > 1 data path of the drop-in package: one process per GPU, this rank's contiguous shard of every batch
+    through `forward`, ONE all-gather of the per-shard logits, the gathered [n_total, C] logits on rank 0.
+
+    The reference's analogue is the OpenMP loop over independent images (src/conv2d.cc:125); nothing is exchanged
+    between shards until the logits.  Two modes, same control flow:
+
+    * device mode (default; `torch.distributed` backend "nccl" = RCCL over xGMI): `forward(x)` returns an `i8ie`
+      tensor on the GPU.  Its logits are copied into one of two stage buffers on the compute stream; the all-gather
+      and rank 0's copy to pinned host memory run on a SIDE stream behind an event, so the collective's latency and
+      the wait for the slowest rank overlap the next batch's kernels.  A stage buffer is reused only after the
+      gather that read it has signalled.  Call `_CXX_i8ie.use_stream(torch.cuda.current_stream().cuda_stream, dev)`
+      before the first op so that the engine's kernels and these copies share torch's stream.
+    * host mode (`host_copies=True`; backend "gloo"): `forward(x)` returns an ndarray (or an `i8ie` tensor that is
+      read back); the gather runs on CPU tensors.  This is what the CPU tests and the one-GPU rehearsal use (RCCL
+      refuses two ranks on one device).
+
+    `submit(x)` queues one batch and returns a handle without waiting for the GPU; `result(handle)` returns the
+    gathered logits as an ndarray on rank 0 (None elsewhere).  Submitting batch i + 1 before asking for batch i's
+    result is the depth-2 pipeline bench.py times.  Every rank must make the same sequence of submit() calls
+    (each contains a collective).
+    """
+
+    def __init__(self, forward, n_total, n_classes, rank=None, world=None, host_copies=False, group=None):
+        import torch.distributed as dist
+
+        self.forward = forward
+        self.n_total = int(n_total)
+        self.n_classes = int(n_classes)
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else int(rank)
+        self.world = dist.get_world_size(group) if world is None else int(world)
+        self.start, self.stop = shard_bounds(self.n_total, self.rank, self.world)
+        self.host_copies = bool(host_copies)
+        self._tick = 0
+        self._stage = None
+
+    # ---- which images are mine ---------------------------------------------------------------------------
+    def shard(self, x_all):
+        """This rank's rows of a global batch (any array-like indexed along axis 0)."""
+        return x_all[self.start:self.stop]
+
+    @property
+    def rows(self):
+        return self.stop - self.start
+
+    # ---- device-mode plumbing ----------------------------------------------------------------------------
+    def _device_setup(self):
+        import torch
+
+        self._torch = torch
+        self._stage = [torch.empty((self.rows, self.n_classes), dtype=torch.float32, device="cuda") for _ in range(2)]
+        self._side = torch.cuda.Stream()
+        self._gathered = [None, None]
+        self._host = None
+        if self.rank == 0:
+            self._host = [torch.empty((self.n_total, self.n_classes), dtype=torch.float32).pin_memory() for _ in range(2)]
+
+    def submit(self, x):
+        y = self.forward(x)
+        if self.host_copies:
+            import torch
+
+            local = y.numpy() if hasattr(y, "numpy") and not isinstance(y, np.ndarray) else np.asarray(y)
+            full = gather_rows(torch.from_numpy(np.ascontiguousarray(local, np.float32)), self.n_total, self.group)
+            return ("host", full.numpy() if self.rank == 0 else None)
+        if self._stage is None:
+            self._device_setup()
+        import _CXX_i8ie as cx
+
+        torch = self._torch
+        k = self._tick & 1
+        self._tick += 1
+        main = torch.cuda.current_stream()
+        if self._gathered[k] is not None:
+            main.wait_event(self._gathered[k])  # the gather of two batches ago has finished reading stage[k]
+        cx.copy_to_ptr(y.data, self._stage[k].data_ptr())
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._side):     # off the compute stream: the next batch does not wait for the collective
+            self._side.wait_event(ready)
+            full = gather_rows(self._stage[k], self.n_total, self.group)  # RCCL all-gather of the per-shard logits
+            if self.rank == 0:
+                self._host[k].copy_(full, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._gathered[k] = ev
+        return ("dev", k, ev)
+
+    def result(self, handle):
+        if handle[0] == "host":
+            return handle[1]
+        _, k, ev = handle
+        if self.rank != 0:
+            return None
+        ev.synchronize()
+        return self._host[k].numpy().copy()
+
+    def run(self, x):
+        """submit + result: one batch, no pipelining."""
+        return self.result(self.submit(x))

@@ -33,6 +33,26 @@ def main():
     assert np.array_equal(labs, np.arange(n_total) % 10)
     pred = sharding.centred_argmax(got, np.zeros(10, np.float32))
     assert (pred == 9).all()
+    # the package's runner (host mode): a "network" every rank can recompute, pipelined two deep like bench.py
+    def net(x):
+        return x @ np.arange(40, dtype=np.float32).reshape(4, 10) + 1.0
+
+    runner = sharding.ShardedRunner(net, n_total, 10, host_copies=True)
+    assert (runner.start, runner.stop) == (start, stop) and runner.rows == stop - start
+    batches = [np.random.default_rng(s).normal(size=(n_total, 4)).astype(np.float32) for s in range(3)]
+    pending, outs = None, []
+    for xb in batches:
+        h = runner.submit(runner.shard(xb))
+        if pending is not None:
+            outs.append(runner.result(pending))
+        pending = h
+    outs.append(runner.result(pending))
+    for xb, o in zip(batches, outs):
+        if rank == 0:
+            assert o.shape == (n_total, 10) and np.array_equal(o, net(xb)), "runner: gathered logits differ"
+        else:
+            assert o is None
+    assert (runner.run(runner.shard(batches[0])) is None) == (rank != 0)
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d/%d ok rows [%d,%d)" % (rank, world, start, stop))
