@@ -47,6 +47,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 struct FirstArgs {
+  // FUSEQ: the FP32 NCHW input itself; every block quantises the rows of its bands into the LDS patch
+  // (src/quantize_utils.cc:44-52 followed by the grouping of repack_smallc), no intermediate image in HBM
+  const float* x;
+  int xc, xh, xw, xpad;
+  float q_scale, q_zpf, q_rscale;
+  uint32_t q_zp;
   const uint8_t* img;  // grouped image [n][Hp][WG][16], bytes re-biased (^0x80)
   size_t img_bytes;
   int Hp;
@@ -127,7 +133,49 @@ __global__ __launch_bounds__(256) void quantize_repack_kernel(const float* __res
   }
 }
 
-template <int KS>
+// One 16-byte group of the grouped image straight from the FP32 planes: pixels x0 .. x0 + 3 of image row y, three
+// channels + the zero point as fourth byte, out-of-image pixels = the zero point (src/conv2d.cc:24-28), re-biased
+// (^ 0x80).  Split in two so that the twelve loads of the next group fly while the current one is multiplied.
+struct GroupLoad {
+  float v[12];
+  int ok;  // bit px: pixel inside the image
+};
+__device__ __forceinline__ void group_issue(const FirstArgs& p, const __amdgpu_buffer_rsrc_t& rs_img, int yp, int g,
+                                            GroupLoad& L) {
+  // rs_img covers the c planes of ONE image; per-lane offsets are 32-bit, the plane offset rides in soffset
+  const int y = yp - p.xpad, x0 = 4 * g - p.xpad;
+  const bool yin = y >= 0 && y < p.xh;
+  const int yc = y < 0 ? 0 : (y >= p.xh ? p.xh - 1 : y);
+  const int cs4 = p.xh * p.xw * 4;
+  L.ok = 0;
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    const int xx = x0 + px;
+    const int xcl = xx < 0 ? 0 : (xx >= p.xw ? p.xw - 1 : xx);
+    if (yin && xx >= 0 && xx < p.xw) L.ok |= 1 << px;
+    const int voff = (yc * p.xw + xcl) * 4;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)  // unconditional, clamped
+      L.v[ch * 4 + px] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, voff, (ch < p.xc ? ch : 0) * cs4, 0));
+  }
+}
+__device__ __forceinline__ uint4 group_finish(const FirstArgs& p, const GroupLoad& L) {
+  uint32_t wds[4];
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    uint32_t d = p.q_zp * 0x01010101u;
+    if (L.ok & (1 << px)) {
+      d = p.q_zp << 24;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+        d |= (ch < p.xc ? quant_exact(L.v[ch * 4 + px], p.q_scale, p.q_zpf, p.q_rscale) : p.q_zp) << (8 * ch);
+    }
+    wds[px] = d ^ 0x80808080u;
+  }
+  return make_uint4(wds[0], wds[1], wds[2], wds[3]);
+}
+
+template <int KS, bool FUSEQ>
 __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int nthreads = blockDim.x;
@@ -135,7 +183,8 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
   const int hh = lane >> 5;
   const int nwaves = nthreads >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int patch_bytes = (p.PR * p.WG * 16 + 1023) & ~1023;  // LDS pitch of a patch: whole 1 KiB DMA pieces
+  // LDS pitch of a patch: whole 1 KiB DMA pieces (the quantising fill writes exactly its groups)
+  const int patch_bytes = FUSEQ ? p.PR * p.WG * 16 : (p.PR * p.WG * 16 + 1023) & ~1023;
   uint8_t* scratch = smem + 2 * patch_bytes + wave * (32 * 36);  // wave-private 32 px x 36 B
 
   // ---- this wave's weight slice -> registers (stays for the whole kernel) ---------------------
@@ -157,7 +206,8 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
 
   const int groups = p.PR * p.WG;
   const int pieces = (groups + 63) >> 6;                    // 1 KiB DMA wave-instructions per patch
-  const int fill_iters = (pieces + nwaves - 1) / nwaves;    // iterations in which every wave issues one
+  // iterations in which every wave issues one DMA piece / every thread quantises one group (FUSEQ)
+  const int fill_iters = FUSEQ ? (groups + nthreads - 1) / nthreads : (pieces + nwaves - 1) / nwaves;
   const FRequant rq = p.rq;
   const int lo = p.relu_lo;
   const float lof = (float)lo;
@@ -187,7 +237,22 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
   int band = blockIdx.x;
   if (band >= p.total_bands) return;
   int cur = 0;
-  {
+  auto image_rsrc = [&](int img) -> __amdgpu_buffer_rsrc_t {
+    const size_t per = (size_t)p.xc * p.xh * p.xw;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)img * per), 0, (int)(per * 4), 0x00020000);
+  };
+  // FUSEQ: group gi of a patch = patch row gi / WG, group gi % WG; thread t owns groups t, t + nthreads, ...
+  const int g_step_row = nthreads / p.WG, g_step_col = nthreads - g_step_row * p.WG;
+  if constexpr (FUSEQ) {
+    int img, rb0, rows;
+    band_origin(band, img, rb0, rows);
+    const __amdgpu_buffer_rsrc_t rs_img = image_rsrc(img);
+    for (int gi = tid; gi < groups; gi += nthreads) {
+      GroupLoad L;
+      group_issue(p, rs_img, rb0 * p.sh + gi / p.WG, gi % p.WG, L);
+      *reinterpret_cast<uint4*>(smem + (size_t)gi * 16) = group_finish(p, L);
+    }
+  } else {
     const __amdgpu_buffer_rsrc_t rs0 = band_rsrc(band);
     for (int q = wave_u; q < pieces; q += nwaves) dma_piece(rs0, smem, q);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -201,7 +266,14 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
     const int ntiles = (npix + 31) >> 5;
     const int nband = band + gridDim.x;
     const bool has_next = nband < p.total_bands;
-    const __amdgpu_buffer_rsrc_t nrs = band_rsrc(has_next ? nband : band);
+    const __amdgpu_buffer_rsrc_t nrs = band_rsrc((has_next && !FUSEQ) ? nband : band);
+    // FUSEQ: this thread's walk over the next band's groups (row, group) and the loads in flight for the next one
+    int nimg = 0, nrb0 = 0, nrows = 0, frow = tid / p.WG, fcol = tid - (tid / p.WG) * p.WG;
+    GroupLoad nxt;
+    nxt.ok = 0;
+    if (FUSEQ && has_next) band_origin(nband, nimg, nrb0, nrows);
+    const __amdgpu_buffer_rsrc_t rs_nimg = image_rsrc(FUSEQ ? nimg : 0);
+    if (FUSEQ && has_next && tid < groups) group_issue(p, rs_nimg, nrb0 * p.sh + frow, fcol, nxt);
     const uint8_t* patch = smem + cur * patch_bytes;
     uint8_t* npatch = smem + (cur ^ 1) * patch_bytes;
     const int iters = ntiles > fill_iters ? ntiles : fill_iters;
@@ -213,7 +285,22 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
 
     for (int it = 0; it < iters; ++it) {
       // the next band's patch streams in beside the tiles of this band: one DMA piece per wave per iteration
-      {
+      if constexpr (FUSEQ) {
+        // group `it * nthreads + tid` of the next band: its loads were issued one iteration ago; issue the next
+        // group's loads, then quantise this one into the other patch (the MFMAs of this iteration follow)
+        const int gi = it * nthreads + tid;
+        if (has_next && gi < groups) {
+          const GroupLoad cur_l = nxt;
+          frow += g_step_row;
+          fcol += g_step_col;
+          if (fcol >= p.WG) {
+            fcol -= p.WG;
+            ++frow;
+          }
+          if (gi + nthreads < groups) group_issue(p, rs_nimg, nrb0 * p.sh + frow, fcol, nxt);
+          *reinterpret_cast<uint4*>(npatch + (size_t)gi * 16) = group_finish(p, cur_l);
+        }
+      } else {
         const int q = it * nwaves + wave_u;
         if (has_next && q < pieces) dma_piece(nrs, npatch, q);
       }
@@ -273,13 +360,17 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
   }
 }
 
-template <int KS>
-int launch_first(i8ie_ctx* ctx, const FirstArgs& a, int blocks, int threads, size_t lds) {
-  I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_smallc_kernel<KS>),
+template <int KS, bool FUSEQ>
+int launch_first_q(i8ie_ctx* ctx, const FirstArgs& a, int blocks, int threads, size_t lds) {
+  I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_smallc_kernel<KS, FUSEQ>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  conv_smallc_kernel<KS><<<blocks, threads, lds, ctx->stream>>>(a);
+  conv_smallc_kernel<KS, FUSEQ><<<blocks, threads, lds, ctx->stream>>>(a);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
+}
+template <int KS>
+int launch_first(i8ie_ctx* ctx, const FirstArgs& a, int blocks, int threads, size_t lds) {
+  return a.x != nullptr ? launch_first_q<KS, true>(ctx, a, blocks, threads, lds) : launch_first_q<KS, false>(ctx, a, blocks, threads, lds);
 }
 
 }  // namespace
@@ -325,7 +416,18 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
   a.WG = (c.OW - 1) * a.swg + c.KWG;
   a.Hp = (c.OH - 1) * c.stride + c.KH;
   const uint8_t* grouped = c.grouped;
-  if (c.x != nullptr) {
+  // FP32 input: a separate HBM-bound pass writes the grouped u8 image first (default), or, with $I8IE_FIRST_FUSED,
+  // every block quantises its bands inside the patch fill.  Measured on MI355X at batch 1000 (round 2): the fused
+  // form is bit-exact but 0.67 ms against 0.22 + 0.17 ms: ~100 VALU operations per 16-byte group land in waves
+  // that are already VALU-bound (12 VALU per MFMA in the epilogue), the halo rows of every band are quantised
+  // again (x 1.35), and 204 VGPRs leave two blocks per CU instead of three.  Kept as a tested opt-in.
+  static const bool fused_opt = std::getenv("I8IE_FIRST_FUSED") != nullptr;
+  const bool fuse = c.x != nullptr && (fused_opt || ctx->variant == 60);  // (variant 60: per-ctx switch for tests / A-B runs)
+  if (fuse) {
+    a.x = c.x; a.xc = c.c; a.xh = c.h; a.xw = c.w; a.xpad = c.pad;
+    a.q_scale = c.q_scale; a.q_zpf = (float)c.q_zp; a.q_rscale = 1.0f / c.q_scale; a.q_zp = (uint32_t)(c.q_zp & 0xFF);
+  }
+  if (c.x != nullptr && !fuse) {
     const int64_t total = (int64_t)c.n * a.Hp * a.WG;
     I8ieProfScope prof(ctx, "quantize_repack_f32", 0.0, 4.0 * c.n * c.c * c.h * c.w + 16.0 * total);
     int64_t blocks = (total + 255) / 256;
@@ -345,7 +447,8 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
   a.img_bytes = (size_t)c.n * a.Hp * a.WG * 16;
   // rows per band: as many as keep two patches within ~44 KB (3 blocks per CU)
   int RB = 1;
-  size_t patch_budget = 44 * 1024;  // bytes for the two patches of a block
+  size_t patch_budget = fuse ? 50 * 1024 : 44 * 1024;  // bytes for the two patches of a block (fused: taller bands
+                                                        // re-quantise fewer halo rows; 50 KB still fits 3 blocks per CU)
   if (const char* e = std::getenv("I8IE_FIRST_PATCH_KB")) patch_budget = (size_t)std::atoi(e) * 1024;
   while (RB < c.OH && (size_t)(RB * a.sh + c.KH) * a.WG * 16 * 2 <= patch_budget && (RB + 1) * c.OW <= 512) ++RB;
   a.RB = RB;
@@ -363,14 +466,16 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
     a.toff[q] = q < nchunks ? (kh * a.WG + g) * 16 : 0;  // chunks past K carry zero weights
   }
   const int waves = c.N / 32, threads = waves * 64;
-  const size_t lds = (size_t)2 * (((size_t)a.PR * a.WG * 16 + 1023) & ~(size_t)1023) + (size_t)waves * 32 * 36;
+  const size_t patch_lds = fuse ? (size_t)a.PR * a.WG * 16 : (((size_t)a.PR * a.WG * 16 + 1023) & ~(size_t)1023);
+  const size_t lds = 2 * patch_lds + (size_t)waves * 32 * 36;
   int per_cu = 3;  // blocks launched per CU (measured on AlexNet conv1 with the DMA fill: 3 beats 2, 4 and 6)
   if (const char* e = std::getenv("I8IE_FIRST_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : per_cu;
   int blocks = 256 * per_cu;
   if (blocks > a.total_bands) blocks = a.total_bands;
   const double ops = 2.0 * c.n * c.OH * c.OW * (double)c.N * c.c * c.KH * c.KW;
   const double bytes = 16.0 * c.n * a.Hp * a.WG + (double)c.n * c.OH * c.OW * c.N;
-  I8ieProfScope prof(ctx, "conv_smallc_wstat", ops, bytes);
+  const double bytes_f = 4.0 * c.n * c.c * c.h * c.w + (double)c.n * c.OH * c.OW * c.N;
+  I8ieProfScope prof(ctx, fuse ? "conv_smallc_f32in" : "conv_smallc_wstat", ops, fuse ? bytes_f : bytes);
   if (ks_needed <= 6) return launch_first<6>(ctx, a, blocks, threads, lds);
   if (ks_needed <= 10) return launch_first<10>(ctx, a, blocks, threads, lds);
   if (ks_needed <= 17) return launch_first<17>(ctx, a, blocks, threads, lds);

@@ -60,9 +60,11 @@ GEOMS = [
 ]
 
 
+@pytest.mark.parametrize("variant", [0, 60])  # 60: quantize inside the convolution kernel's patch fill (opt-in)
 @pytest.mark.parametrize("geom", GEOMS)
-def test_fused_first_layer_bit_exact(gpu, orc, geom):
+def test_fused_first_layer_bit_exact(gpu, orc, geom, variant):
     n, c, h, w, kc, k, stride, pad = geom
+    abi.ck(abi.lib().i8ie_ctx_set_option(gpu.h, 2, variant))
     rng = np.random.default_rng(sum(geom))
     x = rng.uniform(-2.2, 2.6, (n, c, h, w)).astype(np.float32)
     x.flat[::97] = rng.uniform(-9, 9, x.flat[::97].shape)  # some values outside the no-wrap window (unclamped cast)
@@ -75,6 +77,7 @@ def test_fused_first_layer_bit_exact(gpu, orc, geom):
                         relu, ob)
         assert got is not None, "geometry should be supported"
         assert np.array_equal(got, orc.relu(want, cs["zp_out"]) if relu else want)
+    abi.ck(abi.lib().i8ie_ctx_set_option(gpu.h, 2, 0))
 
 
 def test_unsupported_geometries_say_no(gpu, orc):
