@@ -25,6 +25,7 @@ struct I8ieIgemmCall {
   double Ktrue;
   int ksplit;        // amode 0 only: > 1 = split K over that many slices (partial must hold ksplit*M*N int32)
   int32_t* partial;
+  void** wcache;     // amode 1: slot in the layer handle for weights re-packed by a kernel (i8ie_pconv.hip); may be null
 };
 int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 
@@ -32,3 +33,7 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 // Returns 1 when it took the launch, 0 when the shape is not its (the caller then runs the tiled kernel),
 // < 0 on error.
 int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
+
+// i8ie_pconv.hip: the patch-stationary form of the amode-1 contraction (input patch resident in LDS, weights
+// streamed in fragment order).  Same return convention as i8ie_pp_try_launch.
+int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);

@@ -1,0 +1,451 @@
+// i8ie_pconv.hip -- patch-stationary implicit-GEMM Conv2d over bordered NHWC u8 activations.
+//
+//   C[r][j] = sum_k A_u8[r][k] * W_s8[j][k] + oc[j]     (src/conv2d.cc:131-133: cblas_gemm_s8u8s32 + oc)
+//   out     = relu?(down_scale(C))                      (src/quantize_utils.cc:27-36, src/functional.cc:15-26)
+//
+// What round 2's measurements on MI355X said about the contraction kernels:
+//   * every LDS-DMA piece (1 KiB) costs a CU about 18 cycles that no schedule hid, wherever its bytes come from
+//     (L1, L2 or HBM): a 256 x 256 tile fed by im2col'd K tiles needs 64 pieces per 2048 MFMA cycles;
+//   * the u8 -> s8 xor of the activation fragments is fully exposed (4-5 cycles each, 64 per K tile and wave);
+//   * two waves per SIMD in barrier lockstep expose every stall of either.
+// This kernel removes the first two at the source and does without the third:
+//   * The A operand is not staged K tile by K tile.  The INPUT PATCH of an output band (whole output rows of one
+//     image: 9 rows of AlexNet conv2, a whole 13 x 13 image of conv3-5) is copied into LDS ONCE, re-biased there
+//     once (one xor pass), and every tap of every K step reads its fragments from it: pixel pitch C + 16 bytes,
+//     fragment address = base(pixel) + offset(tap, channel chunk), purely additive.  The im2col redundancy
+//     (9x / 25x) stays inside LDS; DMA pieces per K tile drop from 64 to 32 (the weights).
+//   * Bank conflicts without a swizzle: the MFMA row -> pixel map inside a 16-row tile is permuted (rows 0-3 and
+//     12-15 take the even pixels, rows 4-11 the odd ones) and lane group q reads 16-byte chunk 2q (+1 on odd
+//     k-steps): the 16 lanes ds_read_b128 serves per cycle then hit 16 different slots for any odd pitch / 16.
+//   * Weights are pre-packed in MFMA fragment order for exactly that K walk, so a K tile of B is one contiguous
+//     block (32 KiB for 256 features) that lands in LDS by plain linear LDS-DMA and is read back lane-linear.
+//   * 8 waves (2 along the pixels x 4 along the features, 128 x 64 outputs each), free-running: ONE barrier per
+//     K tile (hand-over of the weight stage), fragments software-pipelined half a k-step ahead.
+//   * N = 384 runs as two feature passes of 192 over the same resident patch; tiles are whole bands, so 1000
+//     images of 13 x 13 give 1000 equal tiles (no 86 %-full last round).
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <type_traits>
+#include <vector>
+
+#include "i8ie_calls.h"
+#include "i8ie_internal.h"
+#include "i8ie_requant.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+constexpr unsigned kRowInvalid = 0xC0000000u;  // beyond any output buffer this kernel accepts (< 2^31 bytes)
+constexpr int kTabPix = 256;                   // pixels per tile at most (16 MFMA row tiles)
+
+struct PCArgs {
+  const uint8_t* A;
+  unsigned a_bytes;
+  unsigned img_pitch, row_pitch, C;
+  int OH, OW, s, KH, KW, CC, Wp;
+  float rcpOW, rcpCC1;
+  int RT, bands, n_tiles;  // output rows per tile, tiles per image, tiles in all
+  int P;                   // LDS pixel pitch (bytes) = C + 16
+  int patch_gran;          // 16-byte granules of a full patch
+  const int8_t* Bf;        // [pass][kt][ks][ntile][lane][16]
+  unsigned bf_bytes;
+  int nkt, kchunks;        // K tiles of 8 chunks; valid 16-byte chunks of K
+  int N, npass;
+  const int32_t* ocp;
+  int Npad;
+  I8ieRequant rq;
+  int relu_lo;
+  uint8_t* out;
+  unsigned out_bytes;
+  int ob, OHp, OWp;
+  int lds_patch, lds_b, lds_ocp, lds_tab, lds_ktab;  // LDS offsets
+  int two_patches;
+};
+
+#define PC_BAR() asm volatile("s_barrier" ::: "memory")
+template <int N>
+__device__ __forceinline__ void pc_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void pc_divmod(int x, int d, float rd, int& qo, int& ro) {  // 0 <= x < 2^23
+  int qq = (int)((float)x * rd);
+  int rr = x - qq * d;
+  if (rr < 0) {
+    rr += d;
+    --qq;
+  } else if (rr >= d) {
+    rr -= d;
+    ++qq;
+  }
+  qo = qq;
+  ro = rr;
+}
+
+extern __shared__ __attribute__((aligned(16))) uint8_t pc_smem[];
+
+// MFMA row r of a 16-row tile <-> pixel offset inside the tile (see the header: even pixels for rows 0-3, 12-15)
+__device__ __forceinline__ int pc_row_to_pix(int r) { return (r < 4) ? 2 * r : (r >= 12 ? 2 * (r - 8) : 2 * (r - 4) + 1); }
+
+// TMW: 16-pixel MFMA tiles per wave (2 waves along the pixels); NTW: 16-feature tiles per wave (4 waves along the
+// features, block = 64 NTW features per pass); NST: weight stages in LDS (2 or 3)
+template <int TMW, int NTW, int NST>
+__global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
+  uint8_t* const smem = pc_smem;
+  constexpr int BN = NTW * 64;
+  constexpr int STAGE = BN * 128;      // one K tile of weights: 2 k-steps x (BN / 16) fragment blocks of 1 KiB
+  constexpr int PW = STAGE / 1024 / 8; // DMA pieces per wave and K tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lq = lane >> 4, lr = lane & 15;
+
+  // ---- tiles of this block: XCD-contiguous ranges, consecutive tiles to the blocks of one XCD
+  const int per = (int)gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int Tx = (p.n_tiles + 7) >> 3;
+  const int t_lo = xcd * Tx;
+  const int t_hi = t_lo + Tx < p.n_tiles ? t_lo + Tx : p.n_tiles;
+  int tile = t_lo + jb;
+  if (tile >= t_hi) return;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.A), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.Bf), 0, p.bf_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+
+  // ---- per-kernel tables in LDS: oc', and for pixel i of a tile its window origin in the patch / its output row
+  for (int i = tid; i < p.npass * BN; i += 512) reinterpret_cast<int*>(smem + p.lds_ocp)[i] = i < p.Npad ? p.ocp[i] : 0;
+  const int PT = p.RT * p.OW;
+  for (int i = tid; i < kTabPix; i += 512) {
+    int oy, ox;
+    pc_divmod(i < PT ? i : 0, p.OW, p.rcpOW, oy, ox);
+    reinterpret_cast<unsigned*>(smem + p.lds_tab)[i] = (unsigned)((oy * p.s) * p.Wp + ox * p.s) * (unsigned)p.P;
+    reinterpret_cast<unsigned*>(smem + p.lds_tab)[kTabPix + i] = (unsigned)(oy * p.OWp + ox) * (unsigned)p.N;
+  }
+  for (int i = tid; i < p.nkt * 8; i += 512) {
+    const int ci = 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1);
+    int tap, cc, kh, kw;
+    pc_divmod(ci, p.CC, 1.0f / (float)p.CC, tap, cc);
+    pc_divmod(tap, p.KW, 1.0f / (float)p.KW, kh, kw);
+    reinterpret_cast<unsigned*>(smem + p.lds_ktab)[i] = ci < p.kchunks ? (unsigned)(kh * p.Wp + kw) * (unsigned)p.P + (unsigned)cc * 16u : 0u;
+  }
+  __syncthreads();
+  // this lane's rows: tile (wm * TMW + mi), MFMA row lr -> pixel index inside the band
+  const int pix0 = wm * TMW * 16 + pc_row_to_pix(lr);
+  unsigned abase[TMW];
+#pragma unroll
+  for (int mi = 0; mi < TMW; ++mi) {
+    const int pi = pix0 + mi * 16;
+    abase[mi] = reinterpret_cast<const unsigned*>(smem + p.lds_tab)[pi < kTabPix ? pi : 0];
+  }
+  const int colb = wn * (NTW * 16);  // first feature of this wave inside the pass
+
+  // ---- the patch of a tile -> LDS (pixel pitch P: C bytes + one pad chunk), then one xor pass (u8 -> s8)
+  const int CC1 = p.CC + 1;
+  auto patch_fill = [&](int t, int dst) {
+    const int img = t / p.bands, band = t - img * p.bands;
+    const unsigned src0 = (unsigned)img * p.img_pitch + (unsigned)(band * p.RT * p.s) * p.row_pitch;
+    for (int g0 = 0; g0 < p.patch_gran; g0 += 512) {
+      const int g = g0 + tid;
+      int pix, ch;
+      pc_divmod(g, CC1, p.rcpCC1, pix, ch);
+      const unsigned so = src0 + (unsigned)pix * p.C + (unsigned)(ch < p.CC ? ch : 0) * 16u;  // (bounds: the descriptor)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(smem + dst + (g0 + wave * 64) * 16), 16,
+                                               (int)so, 0, 0, 0);
+    }
+  };
+  auto patch_xor = [&](int dst) {
+    for (int g = tid; g < p.patch_gran; g += 512) {
+      v4i* q = reinterpret_cast<v4i*>(smem + dst + g * 16);
+      *q = *q ^ (int)0x80808080;
+    }
+  };
+  // ---- one K tile of weights (pass, kt) -> stage st: a contiguous block, PW pieces per wave
+  auto fill_B = [&](int pass, int kt, int st) {
+    const unsigned src = ((unsigned)pass * (unsigned)p.nkt + (unsigned)kt) * (unsigned)STAGE;
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(smem + p.lds_b + st * STAGE + (j * 8 + wave) * 1024), 16,
+                                               (int)(src + (unsigned)((j * 8 + wave) * 1024 + lane * 16)), 0, 0, 0);
+  };
+
+  v4i acc[TMW][NTW];
+  const I8ieRequant rq = p.rq;
+  const int lo = p.relu_lo;
+  const float lof = (float)lo;
+
+  // this lane's walk over K: chunk ci = 8 kt + 2 q + ks -> tap ci / CC = (kh, kw), channel chunk ci % CC; the
+  // patch offsets of all (kt, ks, q) sit in an LDS table (chunks past K: offset 0, their weights are zero)
+  auto k_at = [&](int kt, int ks) { return reinterpret_cast<const unsigned*>(smem + p.lds_ktab)[kt * 8 + ks * 4 + lq]; };
+  // the last row tile of the upper wave row may not exist (169 pixels = 10.6 tiles): skipped, wave-uniformly
+  const bool ghost = (wm * TMW + TMW - 1) * 16 >= PT;
+
+  constexpr int HT = (TMW + 1) / 2;  // row tiles per half (fragments are fetched half a k-step ahead)
+  v4i Alo[2][HT], Ahi[HT], Bq[2][NTW];
+  auto load_A = [&](v4i (&dst)[HT], int half, int patch, unsigned koff) {
+#pragma unroll
+    for (int i = 0; i < HT; ++i) {
+      const int mi = half * HT + i;
+      if (mi < TMW) dst[i] = *reinterpret_cast<const v4i*>(smem + patch + abase[mi] + koff);
+    }
+  };
+  auto load_B = [&](v4i (&dst)[NTW], int st, int ks) {
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni)
+      dst[ni] = *reinterpret_cast<const v4i*>(smem + p.lds_b + st * STAGE + ((ks * (BN / 16) + wn * NTW + ni) * 1024) + lane * 16);
+  };
+  auto mfma_half = [&](const v4i (&a)[HT], const v4i (&b)[NTW], int half) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < HT; ++i) {
+      const int mi = half * HT + i;
+      if (mi < TMW && !(mi == TMW - 1 && ghost)) {
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni)
+          asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc[mi][ni]) : "v"(b[ni]), "v"(a[i]));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  auto epilogue = [&](int t, int pass) {
+    const int img = t / p.bands, band = t - img * p.bands;
+    const int oy0 = band * p.RT;
+    const int rows = p.OH - oy0 < p.RT ? p.OH - oy0 : p.RT;
+    const int valid = rows * p.OW;
+    const unsigned obase = ((unsigned)(img * p.OHp + oy0 + p.ob) * (unsigned)p.OWp + (unsigned)p.ob) * (unsigned)p.N;
+    const int n0 = pass * BN + colb;
+#pragma unroll
+    for (int mi = 0; mi < TMW; ++mi) {
+      const int pi = pix0 + mi * 16;
+      const unsigned rowoff = pi < valid ? obase + reinterpret_cast<const unsigned*>(smem + p.lds_tab)[kTabPix + pi] : kRowInvalid;
+      uint32_t d[NTW];
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni) {
+        const v4i c = acc[mi][ni];
+        const int cv[4] = {c.x, c.y, c.z, c.w};
+        d[ni] = i8ie_requant_pack4(cv, rq, lo, lof);
+      }
+#pragma unroll
+      for (int ni = 0; ni + 1 < NTW; ni += 2) {
+        // rows of 16 lanes: odd rows of d[ni] <-> even rows of d[ni + 1]: every lane then holds 8 consecutive features
+        const auto sw = __builtin_amdgcn_permlane16_swap(d[ni], d[ni + 1], false, false);
+        const int col = n0 + ni * 16 + 16 * (lq & 1) + 8 * (lq >> 1);
+        v2u val;
+        val.x = sw[0];
+        val.y = sw[1];
+        __builtin_amdgcn_raw_buffer_store_b64(val, rsO, (int)((col < p.N && rowoff != kRowInvalid) ? rowoff + (unsigned)col : kRowInvalid), 0, 0);
+      }
+      if (NTW & 1) {  // the odd last feature tile: 4 features per lane
+        const int col = n0 + (NTW - 1) * 16 + 4 * lq;
+        __builtin_amdgcn_raw_buffer_store_b32(d[NTW - 1], rsO, (int)((col < p.N && rowoff != kRowInvalid) ? rowoff + (unsigned)col : kRowInvalid), 0, 0);
+      }
+    }
+  };
+
+  // =============================== tile loop ===========================================================
+  // Weight stages: K tile kt sits in stage kt % NST.  After the barrier of K tile kt nobody reads that stage any
+  // more, so it takes K tile kt + NST; before the barrier every wave has waited for its own pieces of K tile kt + 1
+  // (all but the (NST - 2) fills issued after them).  After the LAST barrier of a pass no LDS read is left at all
+  // (fragments are in registers): the next tile's patch is requested there, under the last MFMAs and the epilogue.
+  patch_fill(tile, p.lds_patch);
+  for (; tile < t_hi; tile += per) {
+    const int patch = p.lds_patch;
+    for (int pass = 0; pass < p.npass; ++pass) {
+#pragma unroll
+      for (int s = 0; s < NST; ++s)
+        if (s < p.nkt) fill_B(pass, s, s);
+      pc_wait_vm<0>();
+      __syncthreads();
+      if (pass == 0) {
+        patch_xor(patch);
+        __syncthreads();
+      }
+      // accumulators start as oc'[j] (C = sum + oc', exact)
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni) {
+        const v4i o = *reinterpret_cast<const v4i*>(smem + p.lds_ocp + (pass * BN + colb + ni * 16 + 4 * lq) * 4);
+#pragma unroll
+        for (int mi = 0; mi < TMW; ++mi) acc[mi][ni] = o;
+      }
+      unsigned k0 = k_at(0, 0), k1;
+      load_A(Alo[0], 0, patch, k0);
+      load_B(Bq[0], 0, 0);
+      int st = 0;
+#pragma clang loop unroll(disable)
+      for (int kt = 0; kt < p.nkt; ++kt) {
+        // ---- k-step 0 (chunk 2 q)
+        k1 = k_at(kt, 1);
+        load_A(Ahi, 1, patch, k0);
+        mfma_half(Alo[0], Bq[0], 0);
+        load_A(Alo[1], 0, patch, k1);
+        load_B(Bq[1], st, 1);
+        if (kt + 1 < p.nkt) k0 = k_at(kt + 1, 0);
+        mfma_half(Ahi, Bq[0], 1);
+        // ---- k-step 1 (chunk 2 q + 1)
+        load_A(Ahi, 1, patch, k1);
+        mfma_half(Alo[1], Bq[1], 0);
+        if (kt + NST - 1 < p.nkt) pc_wait_vm<(NST - 2) * PW>(); else pc_wait_vm<0>();
+        PC_BAR();
+        if (kt + NST < p.nkt) fill_B(pass, kt + NST, st);
+        const int nst = st + 1 == NST ? 0 : st + 1;
+        if (kt + 1 < p.nkt) {
+          load_A(Alo[0], 0, patch, k0);
+          load_B(Bq[0], nst, 0);
+        } else if (pass + 1 == p.npass && tile + per < t_hi) {
+          patch_fill(tile + per, p.lds_patch);
+        }
+        mfma_half(Ahi, Bq[1], 1);
+        st = nst;
+      }
+      epilogue(tile, pass);
+    }
+  }
+  pc_wait_vm<0>();
+}
+
+// ---- weights in fragment order for this kernel's K walk: [pass][kt][ks][ntile][lane][16] --------------------
+__global__ __launch_bounds__(256) void pconv_pack_kernel(const int8_t* __restrict__ B, int8_t* __restrict__ Bf, int64_t total16,
+                                                         int Kpad, int Npad, int kchunks, int nkt, int bn) {
+  const int nt = bn / 16;
+  const int64_t gstride = (int64_t)gridDim.x * 256;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total16; e += gstride) {
+    const int lane = (int)(e & 63);
+    int64_t t = e >> 6;
+    const int ntile = (int)(t % nt);
+    t /= nt;
+    const int ks = (int)(t & 1);
+    t >>= 1;
+    const int kt = (int)(t % nkt);
+    const int pass = (int)(t / nkt);
+    const int q = lane >> 4, r = lane & 15;
+    const int chunk = 8 * kt + 2 * q + ks;
+    const int n = pass * bn + ntile * 16 + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (chunk < kchunks && chunk * 16 < Kpad && n < Npad) v = *reinterpret_cast<const uint4*>(B + (size_t)n * Kpad + (size_t)chunk * 16);
+    reinterpret_cast<uint4*>(Bf)[e] = v;
+  }
+}
+
+template <int TMW, int NTW, int NST>
+int launch_pc(i8ie_ctx* ctx, const PCArgs& a, int grid, int lds) {
+  static bool raised[64] = {};
+  const int dev = ctx->device & 63;
+  if (!raised[dev]) {
+    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<TMW, NTW, NST>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    raised[dev] = true;
+  }
+  pconv_kernel<TMW, NTW, NST><<<grid, 512, lds, ctx->stream>>>(a);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+}  // namespace
+
+int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
+  if (c.amode != 1 || c.acc != nullptr || c.biasf != nullptr || c.wcache == nullptr) return 0;
+  if (c.N % 16 != 0 || c.N < 192 || c.Npad > 1024 || c.C < 32 || c.C % 32 != 0 || c.sh != c.sw) return 0;
+  if ((reinterpret_cast<uintptr_t>(c.out) & 15u) != 0) return 0;
+  const int P = c.OH * c.OW;
+  const int n_img = c.M / P;
+  if (n_img * P != c.M || n_img < 64) return 0;  // whole images, and enough of them to fill the chip
+  // feature passes: 256 wide, or 192 wide when that divides N better (384 = 2 x 192)
+  const int bn = (c.N % 256 == 0) ? 256 : (c.N % 192 == 0 ? 192 : 256);
+  const int npass = (c.N + bn - 1) / bn;
+  // output rows per tile: as many whole rows as fit 256 pixels (16 MFMA row tiles)
+  int RT = 256 / c.OW;
+  if (RT < 1) return 0;
+  if (RT > c.OH) RT = c.OH;
+  const int bands = (c.OH + RT - 1) / RT;
+  const int PT = RT * c.OW;
+  const int TM = (PT + 15) / 16;
+  if (TM < 9) return 0;  // (small images: the tiled kernel packs several of them into a tile)
+  const int TMW = TM <= 12 ? 6 : 8;
+  const int CC = c.C / 16, Pp = c.C + 16;
+  const int PR = (RT - 1) * c.sh + c.KH;
+  const int ppix = PR * c.Wp;
+  const int patch_gran = (ppix * (CC + 1) + 511) / 512 * 512;
+  const int kchunks = c.KH * c.KW * CC;
+  const int nkt = (kchunks + 7) / 8;
+  if (nkt < 2 || patch_gran >= (1 << 22)) return 0;
+  const size_t out_pixels = (size_t)n_img * (c.OH + 2 * c.ob) * (c.OW + 2 * c.ob);
+  const size_t out_bytes = out_pixels * (size_t)c.N;
+  if (out_bytes >= ((size_t)1 << 31) || c.a_bytes >= ((size_t)1 << 32) - 4096) return 0;
+  // LDS plan: [patch (x2 if it fits)] [NST weight stages] [oc'] [tables]
+  const int stage = bn * 128;
+  const int fixed = npass * bn * 4 + 2 * kTabPix * 4 + nkt * 32;
+  int nst = 3;
+  const int two = 0;
+  auto need = [&](int nst_) { return patch_gran * 16 + nst_ * stage + fixed; };
+  if (need(nst) > 160 * 1024) nst = 2;
+  if (need(nst) > 160 * 1024) return 0;
+
+  // ---- fragment-packed weights (once per layer: the slot lives in the layer handle)
+  const size_t bf_bytes = (size_t)npass * nkt * stage;
+  if (*c.wcache == nullptr) {
+    void* buf = nullptr;
+    I8IE_TRY(i8ie_malloc(ctx, bf_bytes, &buf));
+    const int64_t total16 = (int64_t)(bf_bytes / 16);
+    int64_t blocks = (total16 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    pconv_pack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.B, (int8_t*)buf, total16, c.Kpad, c.Npad, kchunks, nkt, bn);
+    I8IE_LAUNCH_CHECK();
+    *c.wcache = buf;
+  }
+
+  PCArgs a{};
+  a.A = c.A;
+  a.a_bytes = (unsigned)c.a_bytes;
+  a.C = (unsigned)c.C;
+  a.row_pitch = (unsigned)c.Wp * (unsigned)c.C;
+  a.img_pitch = (unsigned)c.Hp * a.row_pitch;
+  a.OH = c.OH; a.OW = c.OW; a.s = c.sh; a.KH = c.KH; a.KW = c.KW; a.CC = CC; a.Wp = c.Wp;
+  a.rcpOW = 1.0f / (float)c.OW;
+  a.rcpCC1 = 1.0f / (float)(CC + 1);
+  a.RT = RT; a.bands = bands; a.n_tiles = n_img * bands;
+  a.P = Pp;
+  a.patch_gran = patch_gran;
+  a.Bf = (const int8_t*)*c.wcache;
+  a.bf_bytes = (unsigned)bf_bytes;
+  a.nkt = nkt; a.kchunks = kchunks;
+  a.N = c.N; a.npass = npass;
+  a.ocp = c.ocp; a.Npad = c.Npad;
+  a.rq = i8ie_make_requant(c.s_in, c.s_w, c.s_out, c.zp_out);
+  a.relu_lo = c.relu ? c.zp_out : 0;
+  a.out = c.out;
+  a.out_bytes = (unsigned)out_bytes;
+  a.ob = c.ob; a.OHp = c.OH + 2 * c.ob; a.OWp = c.OW + 2 * c.ob;
+  a.two_patches = two;
+  a.lds_patch = 0;
+  a.lds_b = patch_gran * 16 * (two ? 2 : 1);
+  a.lds_ocp = a.lds_b + nst * stage;
+  a.lds_tab = a.lds_ocp + npass * bn * 4;
+  a.lds_ktab = a.lds_tab + 2 * kTabPix * 4;
+  const int lds = a.lds_ktab + nkt * 32;
+
+  static hipDeviceProp_t props[64];
+  static bool have[64] = {};
+  const int dev = ctx->device & 63;
+  if (!have[dev]) {
+    I8IE_HIP_TRY(hipGetDeviceProperties(&props[dev], ctx->device));
+    have[dev] = true;
+  }
+  int grid = props[dev].multiProcessorCount / 8 * 8;
+  if (grid < 8) grid = 8;
+  const double ops = 2.0 * c.M * c.N * c.Ktrue;
+  const double bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
+  char tag[64];
+  snprintf(tag, sizeof(tag), "pconv_%dx%d|M%d,N%d,K%d", TMW * 32, bn, c.M, c.N, c.Kchunks * 16);
+  char nm[32];
+  snprintf(nm, sizeof(nm), "pconv_%dx%d", TMW * 32, bn);
+  I8ieProfScope prof(ctx, ctx->prof ? tag : nm, ops, bytes);
+  int rc;
+  if (TMW == 8 && bn == 256) rc = nst == 3 ? launch_pc<8, 4, 3>(ctx, a, grid, lds) : launch_pc<8, 4, 2>(ctx, a, grid, lds);
+  else if (TMW == 6 && bn == 256) rc = nst == 3 ? launch_pc<6, 4, 3>(ctx, a, grid, lds) : launch_pc<6, 4, 2>(ctx, a, grid, lds);
+  else if (TMW == 6 && bn == 192) rc = nst == 3 ? launch_pc<6, 3, 3>(ctx, a, grid, lds) : launch_pc<6, 3, 2>(ctx, a, grid, lds);
+  else rc = nst == 3 ? launch_pc<8, 3, 3>(ctx, a, grid, lds) : launch_pc<8, 3, 2>(ctx, a, grid, lds);
+  return rc == I8IE_OK ? 1 : rc;
+}

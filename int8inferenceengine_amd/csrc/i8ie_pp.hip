@@ -195,7 +195,13 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
   };
   // weights: every CU streams the same panel once per tile and never re-reads a line, so they go around the L1
   // (sc1: served by L2 as usual) and leave it to the activation windows, whose K tiles overlap
+  v4i sinkv = {0, 0, 0, 0};
   auto dma_b = [&](const __amdgpu_buffer_rsrc_t& rs, int lds_off, unsigned voff, int soff) {
+    if (DBG & 65536) {  // timing experiment: the same bytes as an ordinary load to VGPRs (no LDS write)
+      const v4i v = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0));
+      asm volatile("" ::"v"(v));
+      return;
+    }
     if (DBG & 8192)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + lds_off), 16,
                                                (int)voff, soff, 0, 16);
@@ -212,7 +218,8 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
   // when it does not: two per load slot made that slot 1.7 x the MFMA slot)
   auto fill_A = [&](int st, int a, const unsigned (&off)[2], unsigned koff, int j) {
     if (DBG & 32) return;
-    dma(rsA, st + a * kHalf + (j * 64 + wave * 8) * 128, (DBG & 128) ? ((off[j] + koff) & 0xFFFFu) : off[j] + koff, 0);
+    dma(rsA, st + a * kHalf + (j * 64 + wave * 8) * 128,
+        (DBG & 32768) ? ((off[j] + koff) & 0xFFFu) : (DBG & 128) ? ((off[j] + koff) & 0xFFFFu) : off[j] + koff, 0);
   };
   auto fill_B = [&](int buf, const unsigned (&off)[2], int kt, int j) {  // buf: LDS offset of the half-tile buffer
     if (DBG & 64) return;
@@ -722,6 +729,8 @@ int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   else if (v == 40) rc = launch_pp<R, true, 1 | 4096>(ctx, a, grid);
   else if (v == 41) rc = launch_pp<R, true, 1 | 8192>(ctx, a, grid);
   else if (v == 42) rc = launch_pp<R, true, 1 | 16384>(ctx, a, grid);
+  else if (v == 43) rc = launch_pp<R, true, 1 | 32768>(ctx, a, grid);  // A sources inside 4 KiB: L1 hits (timing only)
+  else if (v == 44) rc = launch_pp<R, true, 1 | 32 | 65536>(ctx, a, grid);  // no A fills, B as VGPR loads (timing only)
   else if (v == 35) rc = launch_pp<R, true, 1 | 256>(ctx, a, grid);
   else if (v == 36) rc = launch_pp<R, true, 1 | 512>(ctx, a, grid);
   else if (v == 38) rc = launch_pp<R, true, 8 | 2048 | 1>(ctx, a, grid);

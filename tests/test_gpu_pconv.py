@@ -1,0 +1,112 @@
+"""The patch-stationary convolution kernel (csrc/i8ie_pconv.hip) against the oracle, through the C-ABI.
+
+Every output byte of the whole batch is compared.  Geometries hit: one feature pass of 256, two passes of 192
+(N = 384), two passes of 256 with the second partly empty (N = 320), one pass of 192; row tiles 11 (one ghost
+tile), 13, 16; K tails inside a K tile; stride 2; images split into several bands with a short last band;
+tile counts that leave blocks with 0 / 1 / several tiles; bordered and plain outputs; with and without the
+fused ReLU.  The profile hooks confirm that the pconv kernel is the one that ran."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import abi
+import synth
+
+pytestmark = pytest.mark.gpu
+
+VARIANT = 50
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    c = abi.Ctx(0)
+    yield c
+    c.close()
+
+
+class _Entry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_uint64), ("total_ms", C.c_double),
+                ("total_ops", C.c_double), ("total_bytes", C.c_double)]
+
+
+def _kernels_run(gpu, fn):
+    lib = abi.lib()
+    abi.ck(lib.i8ie_profile_start(gpu.h, 0))
+    try:
+        res = fn()
+    finally:
+        ents = (_Entry * 64)()
+        n = C.c_int(0)
+        abi.ck(lib.i8ie_profile_stop(gpu.h, ents, 64, C.byref(n)))
+    return res, [ents[i].name.decode().split("|")[0] for i in range(n.value)]
+
+
+GEOMS = [
+    # n, c, h, w, kc, k, stride, pad
+    (300, 128, 13, 13, 256, 3, 1, 1),   # 300 one-image tiles on 256 blocks: some blocks two tiles
+    (130, 32, 13, 13, 256, 3, 1, 1),    # 130 tiles (idle blocks); K = 288 = 18 chunks: 3 K tiles, tail in the last
+    (1100, 64, 13, 13, 384, 3, 1, 1),   # N = 384: two passes of 192; 4-5 tiles per block
+    (260, 32, 13, 13, 320, 3, 1, 1),    # N = 320: two passes of 256, the second a quarter full
+    (70, 32, 31, 31, 256, 3, 2, 1),     # stride 2, 16 x 16 outputs: one band of 256 pixels
+    (100, 96, 27, 27, 256, 5, 1, 2),    # AlexNet conv2 geometry: bands of 9 rows, 300 tiles, K = 2400 (19 K tiles)
+    (97, 64, 14, 14, 192, 3, 1, 1),     # 196 pixels = 13 row tiles; one pass of 192
+    (70, 32, 20, 20, 256, 3, 1, 1),     # 20 x 20: bands of 12 and 8 rows (short last band)
+]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("relu,ob", [(True, 1), (False, 0), (False, 2)])
+def test_pconv_bit_exact(gpu, orc, geom, relu, ob):
+    n, c, h, w, kc, k, stride, pad = geom
+    cs = synth.conv_case(orc, 4321 + sum(geom), n, c, h, w, kc, k, stride, pad)
+
+    def run():
+        lib = abi.lib()
+        abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, VARIANT))
+        try:
+            return gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
+                                           cs["s_out"], cs["zp_out"], stride=stride, pad=pad, in_nhwc=True,
+                                           out_nhwc=True, relu=relu, in_border=pad, out_border=ob, want_acc=False)
+        finally:
+            abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
+
+    (out, _, _), names = _kernels_run(gpu, run)  # (the harness also checks that border bytes stay zp_out)
+    assert any(nm.startswith("pconv") for nm in names), names
+    want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
+    assert np.array_equal(out, want)
+
+
+def test_pconv_wider_input_border_than_padding(gpu, orc):
+    """in_border 2 around a pad-1 convolution: the window origin is shifted into the border, patch rows wrap
+    through border pixels that no valid window touches."""
+    n, c, h, w, kc, k = 80, 64, 13, 13, 256, 3
+    cs = synth.conv_case(orc, 99, n, c, h, w, kc, k, 1, 1)
+    lib = abi.lib()
+    abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, VARIANT))
+    try:
+        out = gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
+                                      cs["s_out"], cs["zp_out"], stride=1, pad=1, in_nhwc=True, out_nhwc=True,
+                                      in_border=2, out_border=0, want_acc=False)[0]
+    finally:
+        abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
+    assert np.array_equal(out, cs["out"])
+
+
+def test_pconv_extreme_operands(gpu, orc):
+    """All-255 activations against +127 / -128 weights (the largest accumulators the layer can produce)."""
+    n, c, h, w, kc, k = 120, 64, 13, 13, 256, 3
+    rng = np.random.default_rng(5)
+    q_in = np.full((n, c, h, w), 255, np.uint8)
+    qw = np.where(rng.random((kc, c, k, k)) < 0.5, 127, -128).astype(np.int8)
+    qb = rng.integers(-128, 128, kc).astype(np.int8)
+    s_in, zp_in, s_w, s_out, zp_out = 0.02, 3, 0.004, 0.9, 131
+    want = orc.conv2d(q_in, qw, qb, 1, 1, np.float32(s_in), zp_in, np.float32(s_w), np.float32(s_out), zp_out)[0]
+    lib = abi.lib()
+    abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, VARIANT))
+    try:
+        out = gpu.layer_forward_fused("conv", q_in, qw, qb, s_in, zp_in, s_w, s_out, zp_out, stride=1, pad=1,
+                                      in_nhwc=True, out_nhwc=True, in_border=1, want_acc=False)[0]
+    finally:
+        abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
+    assert np.array_equal(out, want)
