@@ -63,6 +63,8 @@ struct PCArgs {
   int ob, OHp, OWp;
   int lds_patch, lds_b, lds_ocp, lds_tab, lds_ktab;  // LDS offsets
   int two_patches;
+  int flags;                // timing experiments only (variants 52-55): 1 no weight fills in the K loop, 2 no barrier, 4 no A reads, 8 no B reads
+  unsigned long long* dbg;  // variant 51: per block, cycles spent per phase (wave 0)
 };
 
 #define PC_BAR() asm volatile("s_barrier" ::: "memory")
@@ -91,7 +93,7 @@ __device__ __forceinline__ int pc_row_to_pix(int r) { return (r < 4) ? 2 * r : (
 
 // TMW: 16-pixel MFMA tiles per wave (2 waves along the pixels); NTW: 16-feature tiles per wave (4 waves along the
 // features, block = 64 NTW features per pass); NST: weight stages in LDS (2 or 3)
-template <int TMW, int NTW, int NST>
+template <int TMW, int NTW, int NST, bool GB = false>
 __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   uint8_t* const smem = pc_smem;
   constexpr int BN = NTW * 64;
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   constexpr int HT = (TMW + 1) / 2;  // row tiles per half (fragments are fetched half a k-step ahead)
   v4i Alo[2][HT], Ahi[HT], Bq[2][NTW];
   auto load_A = [&](v4i (&dst)[HT], int half, int patch, unsigned koff) {
+    if (p.flags & 4) return;
 #pragma unroll
     for (int i = 0; i < HT; ++i) {
       const int mi = half * HT + i;
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
     }
   };
   auto load_B = [&](v4i (&dst)[NTW], int st, int ks) {
+    if (p.flags & 8) return;
 #pragma unroll
     for (int ni = 0; ni < NTW; ++ni)
       dst[ni] = *reinterpret_cast<const v4i*>(smem + p.lds_b + st * STAGE + ((ks * (BN / 16) + wn * NTW + ni) * 1024) + lane * 16);
@@ -250,19 +254,30 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   // more, so it takes K tile kt + NST; before the barrier every wave has waited for its own pieces of K tile kt + 1
   // (all but the (NST - 2) fills issued after them).  After the LAST barrier of a pass no LDS read is left at all
   // (fragments are in registers): the next tile's patch is requested there, under the last MFMAs and the epilogue.
+  unsigned long long ph[5] = {0, 0, 0, 0, 0}, tq = 0;
+  auto stamp = [&](int i) {
+    if (p.dbg) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      ph[i] += now - tq;
+      tq = now;
+    }
+  };
+  if (p.dbg) tq = __builtin_amdgcn_s_memtime();
   patch_fill(tile, p.lds_patch);
   for (; tile < t_hi; tile += per) {
     const int patch = p.lds_patch;
     for (int pass = 0; pass < p.npass; ++pass) {
 #pragma unroll
       for (int s = 0; s < NST; ++s)
-        if (s < p.nkt) fill_B(pass, s, s);
+        if (s < p.nkt && !GB) fill_B(pass, s, s);
       pc_wait_vm<0>();
       __syncthreads();
+      stamp(0);  // waiting for the patch / the first weight stages
       if (pass == 0) {
         patch_xor(patch);
         __syncthreads();
       }
+      stamp(1);  // xor pass
       // accumulators start as oc'[j] (C = sum + oc', exact)
 #pragma unroll
       for (int ni = 0; ni < NTW; ++ni) {
@@ -270,40 +285,79 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
 #pragma unroll
         for (int mi = 0; mi < TMW; ++mi) acc[mi][ni] = o;
       }
-      unsigned k0 = k_at(0, 0), k1;
-      load_A(Alo[0], 0, patch, k0);
-      load_B(Bq[0], 0, 0);
-      int st = 0;
+      if constexpr (GB) {
+        // experiment: weights straight from global memory (L2) into registers, no LDS stages, no barrier in the loop
+        auto gload_B = [&](v4i (&dst)[NTW], int kt, int ks) {
+          const unsigned base = ((unsigned)pass * (unsigned)p.nkt + (unsigned)kt) * (unsigned)STAGE + (unsigned)((ks * (BN / 16) + wn * NTW) * 1024 + lane * 16);
+#pragma unroll
+          for (int ni = 0; ni < NTW; ++ni) dst[ni] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(base + ni * 1024), 0, 0));
+        };
+        unsigned k0 = k_at(0, 0), k1;
+        load_A(Alo[0], 0, patch, k0);
+        gload_B(Bq[0], 0, 0);
+        gload_B(Bq[1], 0, 1);
 #pragma clang loop unroll(disable)
-      for (int kt = 0; kt < p.nkt; ++kt) {
-        // ---- k-step 0 (chunk 2 q)
-        k1 = k_at(kt, 1);
-        load_A(Ahi, 1, patch, k0);
-        mfma_half(Alo[0], Bq[0], 0);
-        load_A(Alo[1], 0, patch, k1);
-        load_B(Bq[1], st, 1);
-        if (kt + 1 < p.nkt) k0 = k_at(kt + 1, 0);
-        mfma_half(Ahi, Bq[0], 1);
-        // ---- k-step 1 (chunk 2 q + 1)
-        load_A(Ahi, 1, patch, k1);
-        mfma_half(Alo[1], Bq[1], 0);
-        if (kt + NST - 1 < p.nkt) pc_wait_vm<(NST - 2) * PW>(); else pc_wait_vm<0>();
-        PC_BAR();
-        if (kt + NST < p.nkt) fill_B(pass, kt + NST, st);
-        const int nst = st + 1 == NST ? 0 : st + 1;
-        if (kt + 1 < p.nkt) {
+        for (int kt = 0; kt < p.nkt; ++kt) {
+          const int ktn = kt + 1 < p.nkt ? kt + 1 : kt;
+          k1 = k_at(kt, 1);
+          load_A(Ahi, 1, patch, k0);
+          mfma_half(Alo[0], Bq[0], 0);
+          load_A(Alo[1], 0, patch, k1);
+          k0 = k_at(ktn, 0);
+          mfma_half(Ahi, Bq[0], 1);
+          gload_B(Bq[0], ktn, 0);
+          load_A(Ahi, 1, patch, k1);
+          mfma_half(Alo[1], Bq[1], 0);
           load_A(Alo[0], 0, patch, k0);
-          load_B(Bq[0], nst, 0);
-        } else if (pass + 1 == p.npass && tile + per < t_hi) {
+          mfma_half(Ahi, Bq[1], 1);
+          gload_B(Bq[1], ktn, 1);
+        }
+        if (pass + 1 == p.npass && tile + per < t_hi) {
+          __syncthreads();
           patch_fill(tile + per, p.lds_patch);
         }
-        mfma_half(Ahi, Bq[1], 1);
-        st = nst;
+      } else {
+      unsigned k0 = k_at(0, 0), k1;
+        load_A(Alo[0], 0, patch, k0);
+        load_B(Bq[0], 0, 0);
+        int st = 0;
+#pragma clang loop unroll(disable)
+        for (int kt = 0; kt < p.nkt; ++kt) {
+          // ---- k-step 0 (chunk 2 q)
+          k1 = k_at(kt, 1);
+          load_A(Ahi, 1, patch, k0);
+          mfma_half(Alo[0], Bq[0], 0);
+          load_A(Alo[1], 0, patch, k1);
+          load_B(Bq[1], st, 1);
+          if (kt + 1 < p.nkt) k0 = k_at(kt + 1, 0);
+          mfma_half(Ahi, Bq[0], 1);
+          // ---- k-step 1 (chunk 2 q + 1)
+          load_A(Ahi, 1, patch, k1);
+          mfma_half(Alo[1], Bq[1], 0);
+          if (kt + NST - 1 < p.nkt) pc_wait_vm<(NST - 2) * PW>(); else pc_wait_vm<0>();
+          if (!(p.flags & 2)) PC_BAR();
+          if (kt + NST < p.nkt && !(p.flags & 1)) fill_B(pass, kt + NST, st);
+          const int nst = st + 1 == NST ? 0 : st + 1;
+          if (kt + 1 < p.nkt) {
+            load_A(Alo[0], 0, patch, k0);
+            load_B(Bq[0], nst, 0);
+          } else if (pass + 1 == p.npass && tile + per < t_hi) {
+            patch_fill(tile + per, p.lds_patch);
+          }
+          mfma_half(Ahi, Bq[1], 1);
+          st = nst;
+        }
       }
+      stamp(2);  // K loop
       epilogue(tile, pass);
+      stamp(3);  // epilogue
     }
   }
   pc_wait_vm<0>();
+  if (p.dbg && tid == 0) {
+    for (int i = 0; i < 4; ++i) p.dbg[blockIdx.x * 8 + i] = ph[i];
+    p.dbg[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // ---- weights in fragment order for this kernel's K walk: [pass][kt][ks][ntile][lane][16] --------------------
@@ -329,16 +383,16 @@ __global__ __launch_bounds__(256) void pconv_pack_kernel(const int8_t* __restric
   }
 }
 
-template <int TMW, int NTW, int NST>
+template <int TMW, int NTW, int NST, bool GB = false>
 int launch_pc(i8ie_ctx* ctx, const PCArgs& a, int grid, int lds) {
   static bool raised[64] = {};
   const int dev = ctx->device & 63;
   if (!raised[dev]) {
-    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<TMW, NTW, NST>),
+    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<TMW, NTW, NST, GB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised[dev] = true;
   }
-  pconv_kernel<TMW, NTW, NST><<<grid, 512, lds, ctx->stream>>>(a);
+  pconv_kernel<TMW, NTW, NST, GB><<<grid, 512, lds, ctx->stream>>>(a);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }
@@ -442,10 +496,36 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   char nm[32];
   snprintf(nm, sizeof(nm), "pconv_%dx%d", TMW * 32, bn);
   I8ieProfScope prof(ctx, ctx->prof ? tag : nm, ops, bytes);
+  static unsigned long long* dbg_dev = nullptr;
+  if (ctx->variant == 52) a.flags = 1;
+  if (ctx->variant == 53) a.flags = 3;
+  if (ctx->variant == 54) a.flags = 4;
+  if (ctx->variant == 55) a.flags = 8;
+  if (ctx->variant == 56) a.flags = 15;
+  if (ctx->variant == 57) a.flags = 16;
+  if (ctx->variant >= 51 && ctx->variant <= 57) {
+    if (!dbg_dev) I8IE_HIP_TRY(hipMalloc(&dbg_dev, 4096 * 8 * sizeof(unsigned long long)));
+    I8IE_HIP_TRY(hipMemsetAsync(dbg_dev, 0, 4096 * 8 * sizeof(unsigned long long), ctx->stream));
+    a.dbg = dbg_dev;
+  }
   int rc;
-  if (TMW == 8 && bn == 256) rc = nst == 3 ? launch_pc<8, 4, 3>(ctx, a, grid, lds) : launch_pc<8, 4, 2>(ctx, a, grid, lds);
+  if (ctx->variant == 57 && TMW == 8 && bn == 256) rc = launch_pc<8, 4, 2, true>(ctx, a, grid, lds);
+  else if (ctx->variant == 57 && TMW == 6 && bn == 256) rc = launch_pc<6, 4, 2, true>(ctx, a, grid, lds);
+  else if (ctx->variant == 57 && TMW == 6 && bn == 192) rc = launch_pc<6, 3, 2, true>(ctx, a, grid, lds);
+  else if (TMW == 8 && bn == 256) rc = nst == 3 ? launch_pc<8, 4, 3>(ctx, a, grid, lds) : launch_pc<8, 4, 2>(ctx, a, grid, lds);
   else if (TMW == 6 && bn == 256) rc = nst == 3 ? launch_pc<6, 4, 3>(ctx, a, grid, lds) : launch_pc<6, 4, 2>(ctx, a, grid, lds);
   else if (TMW == 6 && bn == 192) rc = nst == 3 ? launch_pc<6, 3, 3>(ctx, a, grid, lds) : launch_pc<6, 3, 2>(ctx, a, grid, lds);
   else rc = nst == 3 ? launch_pc<8, 3, 3>(ctx, a, grid, lds) : launch_pc<8, 3, 2>(ctx, a, grid, lds);
+  if (rc == I8IE_OK && ctx->variant >= 51 && ctx->variant <= 57 && std::getenv("I8IE_PCONV_STAMPS") != nullptr) {
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    I8IE_HIP_TRY(hipMemcpy(h.data(), dbg_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum[4] = {};
+    for (int b = 0; b < grid; ++b)
+      for (int i = 0; i < 4; ++i) sum[i] += (double)h[(size_t)b * 8 + i];
+    const double tp = (double)a.n_tiles * npass;  // tile passes in all
+    fprintf(stderr, "pconv_stamps v%d M %d N %d K %d (%d tiles x %d passes, %d K tiles, TMW %d bn %d nst %d): per tile pass, cycles: wait for patch/weights %.0f | xor %.0f | K loop %.0f (%.0f per K tile) | epilogue %.0f\n",
+            ctx->variant, c.M, c.N, c.Kchunks * 16, a.n_tiles, npass, nkt, TMW, bn, nst, sum[0] / tp, sum[1] / tp, sum[2] / tp, sum[2] / tp / nkt, sum[3] / tp);
+  }
   return rc == I8IE_OK ? 1 : rc;
 }

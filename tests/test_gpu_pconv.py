@@ -15,7 +15,8 @@ import synth
 
 pytestmark = pytest.mark.gpu
 
-VARIANT = 50
+import os
+VARIANT = int(os.environ.get("I8IE_TEST_PCONV_VARIANT", "50"))
 
 
 @pytest.fixture(scope="module")
