@@ -26,6 +26,7 @@ struct I8ieIgemmCall {
   int ksplit;        // amode 0 only: > 1 = split K over that many slices (partial must hold ksplit*M*N int32)
   int32_t* partial;
   void** wcache;     // amode 1: slot in the layer handle for weights re-packed by a kernel (i8ie_pconv.hip); may be null
+  void** wcache2;    // the same for i8ie_tconv.hip (its K order differs)
 };
 int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 
@@ -37,3 +38,7 @@ int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 // i8ie_pconv.hip: the patch-stationary form of the amode-1 contraction (input patch resident in LDS, weights
 // streamed in fragment order).  Same return convention as i8ie_pp_try_launch.
 int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
+
+// i8ie_tconv.hip: the patch-stationary contraction with two wave teams half a tile apart (epilogues, patch waits
+// and re-bias passes of one team under the MFMAs of the other).  Same return convention.
+int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);

@@ -1052,6 +1052,10 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     const int took = i8ie_pconv_try_launch(ctx, c);
     if (took != 0) return took < 0 ? took : I8IE_OK;
   }
+  if (c.amode == 1 && ctx->variant >= 70 && ctx->variant < 80) {  // the two-team patch-stationary kernel (i8ie_tconv.hip)
+    const int took = i8ie_tconv_try_launch(ctx, c);
+    if (took != 0) return took < 0 ? took : I8IE_OK;
+  }
   IgemmArgs a{};
   a.A = c.A;
   a.a_bytes = (unsigned)c.a_bytes;

@@ -191,6 +191,7 @@ struct i8ie_layer {
   int path = PATH_F;        // conv: PATH_A / PATH_B / PATH_F
   int8_t* Bpack2 = nullptr; // conv paths A/B: [Npad][Kpad2], K ordered (kh, kw, c) / grouped
   int K2 = 0, Kpad2 = 0;    // valid / padded K of Bpack2 (bytes)
+  void* Btconv = nullptr;   // the same for i8ie_tconv.hip
   void* Bpconv = nullptr;   // Bpack2 in the fragment order of i8ie_pconv.hip (made on its first launch)
   int kwg = 0;              // path B: taps per row in 4-pixel groups
   int32_t* wsum = nullptr;  // [n]
@@ -618,7 +619,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
   I8ieIgemmCall c{};
   c.amode = 1; c.M = m * cg.oh * cg.ow;
   c.B = L->Bpack2; c.Kpad = L->Kpad2; c.Npad = L->Npad; c.Kchunks = L->K2 / 16; c.N = L->n; c.ocp = L->ocp;
-  c.biasf = nullptr; c.wcache = &L->Bpconv;
+  c.biasf = nullptr; c.wcache = &L->Bpconv; c.wcache2 = &L->Btconv;
   c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
   c.acc = acc; c.Ktrue = cg.K; c.OH = cg.oh; c.OW = cg.ow;
   const size_t o_bytes = out_layout == I8IE_LAYOUT_NCHW ? i8ie_align_up(out_bytes, 256) : 0;
@@ -740,6 +741,7 @@ int i8ie_layer_destroy(i8ie_layer* L) {
   i8ie_free(ctx, L->Bpack);
   i8ie_free(ctx, L->Bpack2);
   if (L->Bpconv) i8ie_free(ctx, L->Bpconv);
+  if (L->Btconv) i8ie_free(ctx, L->Btconv);
   i8ie_free(ctx, L->wsum);
   i8ie_free(ctx, L->oc);
   i8ie_free(ctx, L->ocp);
