@@ -3,26 +3,33 @@
 //   C[r][j] = sum_k A_u8[r][k] * W_s8[j][k] + oc[j]     (src/conv2d.cc:131-133: cblas_gemm_s8u8s32 + oc)
 //   out     = relu?(down_scale(C))                      (src/quantize_utils.cc:27-36, src/functional.cc:15-26)
 //
-// What round 2's measurements on MI355X said about the contraction kernels:
-//   * every LDS-DMA piece (1 KiB) costs a CU about 18 cycles that no schedule hid, wherever its bytes come from
-//     (L1, L2 or HBM): a 256 x 256 tile fed by im2col'd K tiles needs 64 pieces per 2048 MFMA cycles;
+// What round 2's measurements on MI355X said about the tiled contraction kernels:
+//   * every LDS-DMA piece (1 KiB) costs a CU about 18 cycles that no schedule hid, wherever its bytes come from:
+//     a 256 x 256 tile fed by im2col'd K tiles needs 64 pieces per 2048 MFMA cycles;
 //   * the u8 -> s8 xor of the activation fragments is fully exposed (4-5 cycles each, 64 per K tile and wave);
-//   * two waves per SIMD in barrier lockstep expose every stall of either.
-// This kernel removes the first two at the source and does without the third:
+//   * a barrier per K tile couples 8 waves: every stall of one is a stall of all (13 % on conv2).
+// This kernel removes all three from the K loop:
 //   * The A operand is not staged K tile by K tile.  The INPUT PATCH of an output band (whole output rows of one
-//     image: 9 rows of AlexNet conv2, a whole 13 x 13 image of conv3-5) is copied into LDS ONCE, re-biased there
-//     once (one xor pass), and every tap of every K step reads its fragments from it: pixel pitch C + 16 bytes,
-//     fragment address = base(pixel) + offset(tap, channel chunk), purely additive.  The im2col redundancy
-//     (9x / 25x) stays inside LDS; DMA pieces per K tile drop from 64 to 32 (the weights).
+//     image: 9 rows of AlexNet conv2, a whole 13 x 13 image of conv3-5) is copied into LDS ONCE (LDS-DMA), re-biased
+//     there once (each lane xors the 16 bytes it fetched itself), and every tap of every K step reads its fragments
+//     from it: pixel pitch C + 16 bytes, fragment address = base(pixel) + offset(tap, channel chunk), additive.
+//     The im2col redundancy (9x / 25x) stays inside LDS.
 //   * Bank conflicts without a swizzle: the MFMA row -> pixel map inside a 16-row tile is permuted (rows 0-3 and
 //     12-15 take the even pixels, rows 4-11 the odd ones) and lane group q reads 16-byte chunk 2q (+1 on odd
 //     k-steps): the 16 lanes ds_read_b128 serves per cycle then hit 16 different slots for any odd pitch / 16.
-//   * Weights are pre-packed in MFMA fragment order for exactly that K walk, so a K tile of B is one contiguous
-//     block (32 KiB for 256 features) that lands in LDS by plain linear LDS-DMA and is read back lane-linear.
-//   * 8 waves (2 along the pixels x 4 along the features, 128 x 64 outputs each), free-running: ONE barrier per
-//     K tile (hand-over of the weight stage), fragments software-pipelined half a k-step ahead.
+//   * Weights never touch LDS: they are pre-packed in MFMA fragment order for exactly that K walk, so a wave's
+//     fragment is 1 KiB contiguous, read by one coalesced buffer load straight from L2 into registers, one k-step
+//     ahead (weights of a layer are 0.6-1.3 MB: L2-resident; the two waves that need the same fragment ask for it
+//     at about the same time).  No barrier inside the K loop: 8 waves (2 along the pixels x 4 along the features,
+//     128 x 64 outputs each) run free between the tile's two hand-over points.
 //   * N = 384 runs as two feature passes of 192 over the same resident patch; tiles are whole bands, so 1000
-//     images of 13 x 13 give 1000 equal tiles (no 86 %-full last round).
+//     images of 13 x 13 give 1000 equal tiles.
+//   * The next band's patch is requested when the last K step of a tile has been read (one barrier) and lands
+//     under the epilogue; a counted vmcnt leaves the epilogue's stores in flight.  (Two alternating patch buffers,
+//     where they fit, were measured and bought nothing: vmcnt retires in order, so any wait on a weight fragment
+//     younger than the patch DMA waits for the DMA as well.)
+// History of the design (LDS-staged weights with a barrier per K tile: 5-10 % slower; two wave teams half a tile
+// apart, i8ie_tconv.hip) and the phase stamps behind these statements: DESIGN.md section 4.
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -61,9 +68,9 @@ struct PCArgs {
   uint8_t* out;
   unsigned out_bytes;
   int ob, OHp, OWp;
-  int lds_patch, lds_b, lds_ocp, lds_tab, lds_ktab;  // LDS offsets
-  int two_patches;
-  int flags;                // timing experiments only (variants 52-55): 1 no weight fills in the K loop, 2 no barrier, 4 no A reads, 8 no B reads
+  int lds_patch, lds_ocp, lds_tab, lds_ktab;  // LDS offsets
+  int split;                // 1: a (band, feature pass) pair is a unit of its own (small batches: more units than CUs)
+  int flags;                // experiment (variant 53): 1 = weights of the next pass fetched by the last K tile
   unsigned long long* dbg;  // variant 51: per block, cycles spent per phase (wave 0)
 };
 
@@ -92,13 +99,13 @@ extern __shared__ __attribute__((aligned(16))) uint8_t pc_smem[];
 __device__ __forceinline__ int pc_row_to_pix(int r) { return (r < 4) ? 2 * r : (r >= 12 ? 2 * (r - 8) : 2 * (r - 4) + 1); }
 
 // TMW: 16-pixel MFMA tiles per wave (2 waves along the pixels); NTW: 16-feature tiles per wave (4 waves along the
-// features, block = 64 NTW features per pass); NST: weight stages in LDS (2 or 3)
-template <int TMW, int NTW, int NST, bool GB = false>
+// features, block = 64 NTW features per pass)
+template <int TMW, int NTW>
 __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   uint8_t* const smem = pc_smem;
   constexpr int BN = NTW * 64;
-  constexpr int STAGE = BN * 128;      // one K tile of weights: 2 k-steps x (BN / 16) fragment blocks of 1 KiB
-  constexpr int PW = STAGE / 1024 / 8; // DMA pieces per wave and K tile
+  constexpr int KT_BYTES = BN * 128;  // weights of one K tile of a pass: 2 k-steps x (BN / 16) fragments of 1 KiB
+  constexpr int ST = TMW * ((NTW + 1) / 2);  // buffer stores of one epilogue, per wave (same for every wave)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -107,11 +114,12 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   // ---- tiles of this block: XCD-contiguous ranges, consecutive tiles to the blocks of one XCD
   const int per = (int)gridDim.x >> 3;
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int Tx = (p.n_tiles + 7) >> 3;
+  const int n_units = p.split ? p.n_tiles * p.npass : p.n_tiles;
+  const int Tx = (n_units + 7) >> 3;
   const int t_lo = xcd * Tx;
-  const int t_hi = t_lo + Tx < p.n_tiles ? t_lo + Tx : p.n_tiles;
-  int tile = t_lo + jb;
-  if (tile >= t_hi) return;
+  const int t_hi = t_lo + Tx < n_units ? t_lo + Tx : n_units;
+  int unit = t_lo + jb;
+  if (unit >= t_hi) return;
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.A), 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.Bf), 0, p.bf_bytes, 0x00020000);
@@ -158,21 +166,12 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
                                                (int)so, 0, 0, 0);
     }
   };
-  auto patch_xor = [&](int dst) {
+  auto patch_xor = [&](int dst) {  // every lane re-biases exactly the granules it fetched itself
     for (int g = tid; g < p.patch_gran; g += 512) {
       v4i* q = reinterpret_cast<v4i*>(smem + dst + g * 16);
       *q = *q ^ (int)0x80808080;
     }
   };
-  // ---- one K tile of weights (pass, kt) -> stage st: a contiguous block, PW pieces per wave
-  auto fill_B = [&](int pass, int kt, int st) {
-    const unsigned src = ((unsigned)pass * (unsigned)p.nkt + (unsigned)kt) * (unsigned)STAGE;
-#pragma unroll
-    for (int j = 0; j < PW; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(smem + p.lds_b + st * STAGE + (j * 8 + wave) * 1024), 16,
-                                               (int)(src + (unsigned)((j * 8 + wave) * 1024 + lane * 16)), 0, 0, 0);
-  };
-
   v4i acc[TMW][NTW];
   const I8ieRequant rq = p.rq;
   const int lo = p.relu_lo;
@@ -187,18 +186,16 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   constexpr int HT = (TMW + 1) / 2;  // row tiles per half (fragments are fetched half a k-step ahead)
   v4i Alo[2][HT], Ahi[HT], Bq[2][NTW];
   auto load_A = [&](v4i (&dst)[HT], int half, int patch, unsigned koff) {
-    if (p.flags & 4) return;
 #pragma unroll
     for (int i = 0; i < HT; ++i) {
       const int mi = half * HT + i;
       if (mi < TMW) dst[i] = *reinterpret_cast<const v4i*>(smem + patch + abase[mi] + koff);
     }
   };
-  auto load_B = [&](v4i (&dst)[NTW], int st, int ks) {
-    if (p.flags & 8) return;
+  auto load_B = [&](v4i (&dst)[NTW], int lin, int ks) {  // lin = pass * nkt + kt
+    const unsigned base = (unsigned)lin * (unsigned)KT_BYTES + (unsigned)((ks * (BN / 16) + wn * NTW) * 1024 + lane * 16);
 #pragma unroll
-    for (int ni = 0; ni < NTW; ++ni)
-      dst[ni] = *reinterpret_cast<const v4i*>(smem + p.lds_b + st * STAGE + ((ks * (BN / 16) + wn * NTW + ni) * 1024) + lane * 16);
+    for (int ni = 0; ni < NTW; ++ni) dst[ni] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(base + ni * 1024), 0, 0));
   };
   auto mfma_half = [&](const v4i (&a)[HT], const v4i (&b)[NTW], int half) {
     __builtin_amdgcn_sched_barrier(0);
@@ -228,9 +225,8 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
       uint32_t d[NTW];
 #pragma unroll
       for (int ni = 0; ni < NTW; ++ni) {
-        const v4i c = acc[mi][ni];
-        const int cv[4] = {c.x, c.y, c.z, c.w};
-        d[ni] = i8ie_requant_pack4(cv, rq, lo, lof);
+        const int c4[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
+        d[ni] = i8ie_requant_pack4(c4, rq, lo, lof);
       }
 #pragma unroll
       for (int ni = 0; ni + 1 < NTW; ni += 2) {
@@ -250,11 +246,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   };
 
   // =============================== tile loop ===========================================================
-  // Weight stages: K tile kt sits in stage kt % NST.  After the barrier of K tile kt nobody reads that stage any
-  // more, so it takes K tile kt + NST; before the barrier every wave has waited for its own pieces of K tile kt + 1
-  // (all but the (NST - 2) fills issued after them).  After the LAST barrier of a pass no LDS read is left at all
-  // (fragments are in registers): the next tile's patch is requested there, under the last MFMAs and the epilogue.
-  unsigned long long ph[5] = {0, 0, 0, 0, 0}, tq = 0;
+  unsigned long long ph[4] = {0, 0, 0, 0}, tq = 0;
   auto stamp = [&](int i) {
     if (p.dbg) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -262,22 +254,29 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
       tq = now;
     }
   };
+  const int lin_total = p.npass * p.nkt;
+  const int patch = p.lds_patch;
+  const bool xpre = (p.flags & 1) != 0;  // experiment: the last K tile of a pass already fetches the next pass's weights
+  auto tile_of = [&](int u) { return p.split ? u / p.npass : u; };
+  patch_fill(tile_of(unit), patch);
+  pc_wait_vm<0>();
+  patch_xor(patch);
+  if (xpre) {
+    load_B(Bq[0], 0, 0);
+    load_B(Bq[1], 0, 1);
+  }
+  __syncthreads();
   if (p.dbg) tq = __builtin_amdgcn_s_memtime();
-  patch_fill(tile, p.lds_patch);
-  for (; tile < t_hi; tile += per) {
-    const int patch = p.lds_patch;
-    for (int pass = 0; pass < p.npass; ++pass) {
-#pragma unroll
-      for (int s = 0; s < NST; ++s)
-        if (s < p.nkt && !GB) fill_B(pass, s, s);
-      pc_wait_vm<0>();
-      __syncthreads();
-      stamp(0);  // waiting for the patch / the first weight stages
-      if (pass == 0) {
-        patch_xor(patch);
-        __syncthreads();
+  for (; unit < t_hi; unit += per) {
+    const bool more = unit + per < t_hi;
+    const int tile = tile_of(unit);
+    const int pass_lo = p.split ? unit - tile * p.npass : 0, pass_hi = p.split ? pass_lo + 1 : p.npass;
+    for (int pass = pass_lo; pass < pass_hi; ++pass) {
+      int lin = pass * p.nkt;
+      if (!xpre) {
+        load_B(Bq[0], lin, 0);
+        load_B(Bq[1], lin, 1);
       }
-      stamp(1);  // xor pass
       // accumulators start as oc'[j] (C = sum + oc', exact)
 #pragma unroll
       for (int ni = 0; ni < NTW; ++ni) {
@@ -285,79 +284,48 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
 #pragma unroll
         for (int mi = 0; mi < TMW; ++mi) acc[mi][ni] = o;
       }
-      if constexpr (GB) {
-        // experiment: weights straight from global memory (L2) into registers, no LDS stages, no barrier in the loop
-        auto gload_B = [&](v4i (&dst)[NTW], int kt, int ks) {
-          const unsigned base = ((unsigned)pass * (unsigned)p.nkt + (unsigned)kt) * (unsigned)STAGE + (unsigned)((ks * (BN / 16) + wn * NTW) * 1024 + lane * 16);
-#pragma unroll
-          for (int ni = 0; ni < NTW; ++ni) dst[ni] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(base + ni * 1024), 0, 0));
-        };
-        unsigned k0 = k_at(0, 0), k1;
-        load_A(Alo[0], 0, patch, k0);
-        gload_B(Bq[0], 0, 0);
-        gload_B(Bq[1], 0, 1);
-#pragma clang loop unroll(disable)
-        for (int kt = 0; kt < p.nkt; ++kt) {
-          const int ktn = kt + 1 < p.nkt ? kt + 1 : kt;
-          k1 = k_at(kt, 1);
-          load_A(Ahi, 1, patch, k0);
-          mfma_half(Alo[0], Bq[0], 0);
-          load_A(Alo[1], 0, patch, k1);
-          k0 = k_at(ktn, 0);
-          mfma_half(Ahi, Bq[0], 1);
-          gload_B(Bq[0], ktn, 0);
-          load_A(Ahi, 1, patch, k1);
-          mfma_half(Alo[1], Bq[1], 0);
-          load_A(Alo[0], 0, patch, k0);
-          mfma_half(Ahi, Bq[1], 1);
-          gload_B(Bq[1], ktn, 1);
-        }
-        if (pass + 1 == p.npass && tile + per < t_hi) {
-          __syncthreads();
-          patch_fill(tile + per, p.lds_patch);
-        }
-      } else {
+      // K loop: A fragments half a k-step ahead (LDS), weight fragments one k-step ahead (L2)
       unsigned k0 = k_at(0, 0), k1;
-        load_A(Alo[0], 0, patch, k0);
-        load_B(Bq[0], 0, 0);
-        int st = 0;
+      load_A(Alo[0], 0, patch, k0);
 #pragma clang loop unroll(disable)
-        for (int kt = 0; kt < p.nkt; ++kt) {
-          // ---- k-step 0 (chunk 2 q)
-          k1 = k_at(kt, 1);
-          load_A(Ahi, 1, patch, k0);
-          mfma_half(Alo[0], Bq[0], 0);
-          load_A(Alo[1], 0, patch, k1);
-          load_B(Bq[1], st, 1);
-          if (kt + 1 < p.nkt) k0 = k_at(kt + 1, 0);
-          mfma_half(Ahi, Bq[0], 1);
-          // ---- k-step 1 (chunk 2 q + 1)
-          load_A(Ahi, 1, patch, k1);
-          mfma_half(Alo[1], Bq[1], 0);
-          if (kt + NST - 1 < p.nkt) pc_wait_vm<(NST - 2) * PW>(); else pc_wait_vm<0>();
-          if (!(p.flags & 2)) PC_BAR();
-          if (kt + NST < p.nkt && !(p.flags & 1)) fill_B(pass, kt + NST, st);
-          const int nst = st + 1 == NST ? 0 : st + 1;
-          if (kt + 1 < p.nkt) {
-            load_A(Alo[0], 0, patch, k0);
-            load_B(Bq[0], nst, 0);
-          } else if (pass + 1 == p.npass && tile + per < t_hi) {
-            patch_fill(tile + per, p.lds_patch);
-          }
-          mfma_half(Ahi, Bq[1], 1);
-          st = nst;
-        }
+      for (int kt = 0; kt < p.nkt; ++kt, ++lin) {
+        const int ktn = kt + 1 < p.nkt ? kt + 1 : kt;
+        const int linn = kt + 1 < p.nkt ? lin + 1 : (xpre ? (lin + 1 < lin_total ? lin + 1 : 0) : lin);  // (xpre: not with split)
+        k1 = k_at(kt, 1);
+        load_A(Ahi, 1, patch, k0);
+        mfma_half(Alo[0], Bq[0], 0);
+        load_A(Alo[1], 0, patch, k1);
+        k0 = k_at(ktn, 0);
+        mfma_half(Ahi, Bq[0], 1);
+        load_B(Bq[0], linn, 0);
+        load_A(Ahi, 1, patch, k1);
+        mfma_half(Alo[1], Bq[1], 0);
+        load_A(Alo[0], 0, patch, k0);
+        mfma_half(Ahi, Bq[1], 1);
+        load_B(Bq[1], linn, 1);
       }
-      stamp(2);  // K loop
-      epilogue(tile, pass);
-      stamp(3);  // epilogue
+      stamp(0);  // K loop
+      if (pass + 1 < pass_hi) {
+        epilogue(tile, pass);
+        stamp(1);
+      }
     }
+    // ---- hand-over: everyone is done with the patch -> request the next one -> it lands under the epilogue
+    __syncthreads();
+    if (more) patch_fill(tile_of(unit + per), patch);
+    stamp(2);
+    epilogue(tile, pass_hi - 1);
+    stamp(1);
+    if (more) {
+      pc_wait_vm<ST>();  // all but the epilogue's stores
+      patch_xor(patch);
+    }
+    __syncthreads();
+    stamp(2);
   }
   pc_wait_vm<0>();
-  if (p.dbg && tid == 0) {
-    for (int i = 0; i < 4; ++i) p.dbg[blockIdx.x * 8 + i] = ph[i];
-    p.dbg[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-  }
+  if (p.dbg && tid == 0)
+    for (int i = 0; i < 3; ++i) p.dbg[blockIdx.x * 8 + i] = ph[i];
 }
 
 // ---- weights in fragment order for this kernel's K walk: [pass][kt][ks][ntile][lane][16] --------------------
@@ -383,16 +351,16 @@ __global__ __launch_bounds__(256) void pconv_pack_kernel(const int8_t* __restric
   }
 }
 
-template <int TMW, int NTW, int NST, bool GB = false>
+template <int TMW, int NTW>
 int launch_pc(i8ie_ctx* ctx, const PCArgs& a, int grid, int lds) {
   static bool raised[64] = {};
   const int dev = ctx->device & 63;
   if (!raised[dev]) {
-    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<TMW, NTW, NST, GB>),
+    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<TMW, NTW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised[dev] = true;
   }
-  pconv_kernel<TMW, NTW, NST, GB><<<grid, 512, lds, ctx->stream>>>(a);
+  pconv_kernel<TMW, NTW><<<grid, 512, lds, ctx->stream>>>(a);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }
@@ -428,17 +396,13 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   const size_t out_pixels = (size_t)n_img * (c.OH + 2 * c.ob) * (c.OW + 2 * c.ob);
   const size_t out_bytes = out_pixels * (size_t)c.N;
   if (out_bytes >= ((size_t)1 << 31) || c.a_bytes >= ((size_t)1 << 32) - 4096) return 0;
-  // LDS plan: [patch (x2 if it fits)] [NST weight stages] [oc'] [tables]
-  const int stage = bn * 128;
+  // LDS plan: [patch] [oc'] [tables]
+  const int kt_bytes = bn * 128;
   const int fixed = npass * bn * 4 + 2 * kTabPix * 4 + nkt * 32;
-  int nst = 3;
-  const int two = 0;
-  auto need = [&](int nst_) { return patch_gran * 16 + nst_ * stage + fixed; };
-  if (need(nst) > 160 * 1024) nst = 2;
-  if (need(nst) > 160 * 1024) return 0;
+  if (patch_gran * 16 + fixed > 160 * 1024) return 0;
 
   // ---- fragment-packed weights (once per layer: the slot lives in the layer handle)
-  const size_t bf_bytes = (size_t)npass * nkt * stage;
+  const size_t bf_bytes = (size_t)npass * nkt * kt_bytes;
   if (*c.wcache == nullptr) {
     void* buf = nullptr;
     I8IE_TRY(i8ie_malloc(ctx, bf_bytes, &buf));
@@ -449,6 +413,22 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     I8IE_LAUNCH_CHECK();
     *c.wcache = buf;
   }
+
+  static hipDeviceProp_t props[64];
+  static bool have[64] = {};
+  const int dev = ctx->device & 63;
+  if (!have[dev]) {
+    I8IE_HIP_TRY(hipGetDeviceProperties(&props[dev], ctx->device));
+    have[dev] = true;
+  }
+  int grid = props[dev].multiProcessorCount / 8 * 8;
+  if (grid < 8) grid = 8;
+  // One block per CU walks whole bands: with fewer bands than CUs, the passes of a band become units of their own;
+  // below 3/4 of the CUs even then, the tiled kernel (finer tiles, two blocks per CU) is the faster one (measured
+  // at 125 images: conv3/conv4 0.028/0.038 ms tiled vs 0.035/0.048 ms here) unless the caller forces this kernel.
+  const int n_tiles = n_img * bands;
+  const int split = (n_tiles < grid && npass > 1) ? 1 : 0;
+  if (ctx->variant == 0 && n_tiles * (split ? npass : 1) < grid * 3 / 4) return 0;
 
   PCArgs a{};
   a.A = c.A;
@@ -472,23 +452,14 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.out = c.out;
   a.out_bytes = (unsigned)out_bytes;
   a.ob = c.ob; a.OHp = c.OH + 2 * c.ob; a.OWp = c.OW + 2 * c.ob;
-  a.two_patches = two;
+  a.split = split;
+  a.flags = (ctx->variant == 53 && !split) ? 1 : 0;
   a.lds_patch = 0;
-  a.lds_b = patch_gran * 16 * (two ? 2 : 1);
-  a.lds_ocp = a.lds_b + nst * stage;
+  a.lds_ocp = patch_gran * 16;
   a.lds_tab = a.lds_ocp + npass * bn * 4;
   a.lds_ktab = a.lds_tab + 2 * kTabPix * 4;
   const int lds = a.lds_ktab + nkt * 32;
 
-  static hipDeviceProp_t props[64];
-  static bool have[64] = {};
-  const int dev = ctx->device & 63;
-  if (!have[dev]) {
-    I8IE_HIP_TRY(hipGetDeviceProperties(&props[dev], ctx->device));
-    have[dev] = true;
-  }
-  int grid = props[dev].multiProcessorCount / 8 * 8;
-  if (grid < 8) grid = 8;
   const double ops = 2.0 * c.M * c.N * c.Ktrue;
   const double bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
   char tag[64];
@@ -497,35 +468,26 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   snprintf(nm, sizeof(nm), "pconv_%dx%d", TMW * 32, bn);
   I8ieProfScope prof(ctx, ctx->prof ? tag : nm, ops, bytes);
   static unsigned long long* dbg_dev = nullptr;
-  if (ctx->variant == 52) a.flags = 1;
-  if (ctx->variant == 53) a.flags = 3;
-  if (ctx->variant == 54) a.flags = 4;
-  if (ctx->variant == 55) a.flags = 8;
-  if (ctx->variant == 56) a.flags = 15;
-  if (ctx->variant == 57) a.flags = 16;
-  if (ctx->variant >= 51 && ctx->variant <= 57) {
+  if (ctx->variant == 51) {
     if (!dbg_dev) I8IE_HIP_TRY(hipMalloc(&dbg_dev, 4096 * 8 * sizeof(unsigned long long)));
     I8IE_HIP_TRY(hipMemsetAsync(dbg_dev, 0, 4096 * 8 * sizeof(unsigned long long), ctx->stream));
     a.dbg = dbg_dev;
   }
   int rc;
-  if (ctx->variant == 57 && TMW == 8 && bn == 256) rc = launch_pc<8, 4, 2, true>(ctx, a, grid, lds);
-  else if (ctx->variant == 57 && TMW == 6 && bn == 256) rc = launch_pc<6, 4, 2, true>(ctx, a, grid, lds);
-  else if (ctx->variant == 57 && TMW == 6 && bn == 192) rc = launch_pc<6, 3, 2, true>(ctx, a, grid, lds);
-  else if (TMW == 8 && bn == 256) rc = nst == 3 ? launch_pc<8, 4, 3>(ctx, a, grid, lds) : launch_pc<8, 4, 2>(ctx, a, grid, lds);
-  else if (TMW == 6 && bn == 256) rc = nst == 3 ? launch_pc<6, 4, 3>(ctx, a, grid, lds) : launch_pc<6, 4, 2>(ctx, a, grid, lds);
-  else if (TMW == 6 && bn == 192) rc = nst == 3 ? launch_pc<6, 3, 3>(ctx, a, grid, lds) : launch_pc<6, 3, 2>(ctx, a, grid, lds);
-  else rc = nst == 3 ? launch_pc<8, 3, 3>(ctx, a, grid, lds) : launch_pc<8, 3, 2>(ctx, a, grid, lds);
-  if (rc == I8IE_OK && ctx->variant >= 51 && ctx->variant <= 57 && std::getenv("I8IE_PCONV_STAMPS") != nullptr) {
+  if (TMW == 8 && bn == 256) rc = launch_pc<8, 4>(ctx, a, grid, lds);
+  else if (TMW == 6 && bn == 256) rc = launch_pc<6, 4>(ctx, a, grid, lds);
+  else if (TMW == 6 && bn == 192) rc = launch_pc<6, 3>(ctx, a, grid, lds);
+  else rc = launch_pc<8, 3>(ctx, a, grid, lds);
+  if (rc == I8IE_OK && ctx->variant == 51 && std::getenv("I8IE_PCONV_STAMPS") != nullptr) {
     std::vector<unsigned long long> h((size_t)grid * 8);
     I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
     I8IE_HIP_TRY(hipMemcpy(h.data(), dbg_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum[4] = {};
+    double sum[3] = {};
     for (int b = 0; b < grid; ++b)
-      for (int i = 0; i < 4; ++i) sum[i] += (double)h[(size_t)b * 8 + i];
-    const double tp = (double)a.n_tiles * npass;  // tile passes in all
-    fprintf(stderr, "pconv_stamps v%d M %d N %d K %d (%d tiles x %d passes, %d K tiles, TMW %d bn %d nst %d): per tile pass, cycles: wait for patch/weights %.0f | xor %.0f | K loop %.0f (%.0f per K tile) | epilogue %.0f\n",
-            ctx->variant, c.M, c.N, c.Kchunks * 16, a.n_tiles, npass, nkt, TMW, bn, nst, sum[0] / tp, sum[1] / tp, sum[2] / tp, sum[2] / tp / nkt, sum[3] / tp);
+      for (int i = 0; i < 3; ++i) sum[i] += (double)h[(size_t)b * 8 + i];
+    const double tp = (double)a.n_tiles * npass;  // band passes in all
+    fprintf(stderr, "pconv_stamps v%d M %d N %d K %d (%d tiles x %d passes, %d K tiles, TMW %d bn %d): per tile pass, cycles: K loop %.0f (%.0f per K tile) | epilogue %.0f | hand-over (barriers, patch wait, re-bias) %.0f\n",
+            ctx->variant, c.M, c.N, c.Kchunks * 16, a.n_tiles, npass, nkt, TMW, bn, sum[0] / tp, sum[0] / tp / nkt, sum[1] / tp, sum[2] / tp);
   }
   return rc == I8IE_OK ? 1 : rc;
 }

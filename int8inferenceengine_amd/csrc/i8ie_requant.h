@@ -57,6 +57,9 @@ __device__ __forceinline__ uint32_t i8ie_requant_pack4(const int (&c)[4], const 
   return packed;
 }
 
+// (Measured and dropped: the same estimate two values at a time with v_pk_fma_f32 / v_pk_add_f32 / v_min3_f32,
+// 5.5 instead of 7 instructions per value, made the conv2-5 kernels 8-12 % SLOWER on MI355X: the packed fp32
+// instructions do not issue at the rate of the plain ones next to MFMA waves.  DESIGN.md section 4.)
 // the unguarded estimate alone (kernels compiled for I8IE_RQ_PROVEN): 4 VALU operations per value
 __device__ __forceinline__ uint32_t i8ie_requant_pack4_proven(int c0, int c1, int c2, int c3, float ms, float bias,
                                                               float lof) {

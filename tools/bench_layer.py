@@ -39,6 +39,7 @@ def main():
     rng = np.random.default_rng(0)
     for name in names:
         n, c, h, w, kc, k, stride, pad = LAYERS[name]
+        n = int(os.environ.get("I8IE_BENCH_N", n))
         oh, ow = (h - k + 2 * pad) // stride + 1, (w - k + 2 * pad) // stride + 1
         qw = rng.integers(-63, 64, (kc, c, k, k)).astype(np.int8)
         if os.environ.get("I8IE_BENCH_CONST"):  # constant operands: how much of the rate is data-dependent power?
