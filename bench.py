@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: --batch images PER GPU (global batch = batch x GPUs); default is the strong "
                          "scaling BASELINE.json configs[4] names (global batch fixed, sharded)")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="replay the forward as one HIP graph (int8inferenceengine_amd/graph.py); auto: when this rank's "
+                         "shard is at most 256 images, where the eager forward is launch-bound")
     ap.add_argument("--sync-steps", action="store_true",
                     help="read every batch's logits before launching the next batch (no software pipeline)")
     return ap.parse_args()
@@ -127,15 +130,27 @@ def main():
     cx.synchronize()
     h2d_ms = (time.perf_counter() - t_h2d0) * 1e3
     # N > 1: the package's runner owns the stage buffers, the side stream, the all-gather and rank 0's read-back
+    use_graph = args.graph == "on" or (args.graph == "auto" and (stop - start) <= 256)
+    graphed = None
+    if use_graph:
+        from int8inferenceengine_amd.graph import GraphedForward
+        graphed = GraphedForward(net, x_dev)  # one eager forward, then the same launches recorded as a HIP graph
     runner = sharding.ShardedRunner(net, n_total, 10, rank, world, host_copies=rehearse) if use_dist else None
+    mode = {"eager": False}
 
     state = {"correct": 0, "logits": None}
+
+    def forward(x):
+        return graphed() if (graphed is not None and not mode["eager"]) else net(x)
+
+    if runner is not None:
+        runner.forward = forward
 
     def launch():
         """Queue one batch: quantize -> INT8 layers -> dequantize -> (gather) -> logits towards the host.
         Nothing here waits for the GPU."""
         if not use_dist:
-            return net(x_dev).numpy_async()
+            return forward(x_dev).numpy_async()
         return runner.submit(x_dev)
 
     def consume(h):
@@ -176,7 +191,7 @@ def main():
     run_steps(args.warmup, pipelined)
     barrier()
     torch.cuda.synchronize()
-    if rank == 0 and not os.environ.get("I8IE_BENCH_NO_EVENTS"):
+    if rank == 0 and not os.environ.get("I8IE_BENCH_NO_EVENTS") and graphed is None:
         # HIP events around contraction-kernel launches, on the stream the kernels run on.  Every event
         # packet costs a few microseconds of stream time (bracketing all 9 contraction launches of a step:
         # ~5 % of the step), so the timed region brackets every 5th contraction launch -- coprime with the
@@ -187,7 +202,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = cx.profile_stop() if rank == 0 else {}
+    prof = cx.profile_stop() if (rank == 0 and graphed is None and not os.environ.get("I8IE_BENCH_NO_EVENTS")) else {}
     # untimed: the same batches with the other step discipline, for the record
     barrier()
     torch.cuda.synchronize()
@@ -196,12 +211,14 @@ def main():
     torch.cuda.synchronize()
     barrier()
     other_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    mode["eager"] = True  # the per-kernel breakdown needs individual launches: graph replays are not bracketed
     if rank == 0:  # untimed pass with every launch bracketed: the per-kernel breakdown
         cx.profile_start(mfma_only=False)
         run_steps(args.steps, pipelined)
         full = cx.profile_stop()
     else:
         run_steps(args.steps, pipelined)  # keep the collectives matched
+    mode["eager"] = False
     # ---- untimed: PCIe-inclusive rate.  The FP32 batch starts in pinned host memory, its upload runs on the
     # transfer stream beside the kernels of the batch before (two pinned buffers, two device blocks).
     pcie = None
@@ -387,6 +404,8 @@ def main():
         "prewarm_steps_untimed": prewarm,
         **({"REHEARSAL": "all ranks on one GPU, gloo collectives on host copies: control flow only, not a measurement"}
            if rehearse else {}),
+        "launch_mode": ("one HIP graph replay per batch (%d kernel nodes of %d nodes; int8inferenceengine_amd/graph.py)" % (graphed.kernel_nodes, graphed.nodes)
+                        if graphed is not None else "eager launches"),
         "step_discipline": ("depth-2 software pipeline: batch i+1 is launched before batch i's logits are awaited"
                             if pipelined else "synchronous: logits of batch i read before batch i+1 is launched"),
         ("ms_per_step_synchronous" if pipelined else "ms_per_step_pipelined"): round(other_ms, 4),

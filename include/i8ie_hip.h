@@ -101,6 +101,21 @@ int i8ie_memcpy_d2h(i8ie_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 int i8ie_memcpy_d2d(i8ie_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 int i8ie_memset(i8ie_ctx* ctx, void* dst_dev, int byte, size_t bytes);
 
+/* ---- whole-forward replay as one HIP graph (small per-GPU batches are launch-bound) ----------
+ * Nothing like it in the reference (its forward is a chain of host calls, i8ie/module.py); on the GPU a 125-image
+ * AlexNet shard spends more time between its ~14 dependent launches than inside them.  Between begin and end every
+ * launch and asynchronous copy this ctx issues is recorded instead of run; device blocks freed meanwhile stay owned
+ * by the graph (their addresses are baked into it) until i8ie_graph_destroy.  Run the same calls once eagerly
+ * first: workspace growth, weight re-packing caches and offset vectors must exist before the capture (anything
+ * that would synchronise inside it fails the capture with I8IE_ERR_HIP).  Replays are ordered on the ctx's
+ * stream like any other launch; inputs and outputs are the device buffers the captured calls used. */
+typedef struct i8ie_graph i8ie_graph;
+int i8ie_graph_begin(i8ie_ctx* ctx);
+int i8ie_graph_end(i8ie_ctx* ctx, i8ie_graph** out);
+int i8ie_graph_launch(i8ie_graph* g);
+int i8ie_graph_nodes(i8ie_graph* g, int* kernel_nodes, int* all_nodes);
+int i8ie_graph_destroy(i8ie_graph* g);
+
 /* ---- asynchronous host<->device transfers -------
  * Nothing like it in the reference (its tensors are host arrays, include/tensor.h:26-61); this is
  * what lets a caller overlap the logits read-back and the next batch's upload with the kernels.

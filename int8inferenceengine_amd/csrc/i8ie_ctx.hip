@@ -202,6 +202,10 @@ int i8ie_free(i8ie_ctx* ctx, void* dev) {
   I8iePool* p = pool_of(ctx);
   auto it = p->live.find(dev);
   I8IE_REQUIRE(it != p->live.end(), "pointer was not allocated by i8ie_malloc on this ctx");
+  if (ctx->capture) {  // the graph being captured has this address baked in: it owns the block until it is destroyed
+    static_cast<std::vector<void*>*>(ctx->capture)->push_back(dev);
+    return I8IE_OK;
+  }
   const size_t sz = it->second;
   p->live.erase(it);
   p->bytes_live -= sz;
@@ -456,10 +460,94 @@ int i8ie_memset(i8ie_ctx* ctx, void* dst_dev, int byte, size_t bytes) {
   return I8IE_OK;
 }
 
+struct i8ie_graph {
+  i8ie_ctx* ctx;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  std::vector<void*> held;  // blocks freed during the capture
+};
+
+int i8ie_graph_begin(i8ie_ctx* ctx) {
+  I8IE_REQUIRE(ctx != nullptr, "null ctx");
+  I8IE_REQUIRE(ctx->capture == nullptr, "a capture is already open on this ctx");
+  I8IE_REQUIRE(ctx->prof == nullptr, "per-kernel timing is on: stop it before capturing a graph");
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8IE_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+  ctx->capture = new std::vector<void*>();
+  return I8IE_OK;
+}
+
+int i8ie_graph_end(i8ie_ctx* ctx, i8ie_graph** out) {
+  I8IE_REQUIRE(ctx != nullptr && out != nullptr, "null argument");
+  I8IE_REQUIRE(ctx->capture != nullptr, "no capture is open on this ctx");
+  std::vector<void*>* held = static_cast<std::vector<void*>*>(ctx->capture);
+  ctx->capture = nullptr;
+  auto give_back = [&]() {
+    for (void* b : *held) (void)i8ie_free(ctx, b);
+    delete held;
+  };
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+  if (e != hipSuccess || graph == nullptr) {
+    (void)hipGetLastError();
+    give_back();
+    i8ie_set_error("hipStreamEndCapture: %s (a call inside the capture synchronised or allocated?)", hipGetErrorString(e));
+    return I8IE_ERR_HIP;
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipGraphDestroy(graph);
+    give_back();
+    i8ie_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+    return I8IE_ERR_HIP;
+  }
+  i8ie_graph* g = new i8ie_graph{ctx, graph, exec, std::move(*held)};
+  delete held;
+  *out = g;
+  return I8IE_OK;
+}
+
+int i8ie_graph_launch(i8ie_graph* g) {
+  I8IE_REQUIRE(g != nullptr, "null graph");
+  I8IE_REQUIRE(g->ctx->capture == nullptr, "a graph cannot be replayed inside a capture");
+  I8IE_HIP_TRY(hipGraphLaunch(g->exec, g->ctx->stream));
+  return I8IE_OK;
+}
+
+int i8ie_graph_nodes(i8ie_graph* g, int* kernel_nodes, int* all_nodes) {
+  I8IE_REQUIRE(g != nullptr, "null graph");
+  size_t n = 0;
+  I8IE_HIP_TRY(hipGraphGetNodes(g->graph, nullptr, &n));
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n) I8IE_HIP_TRY(hipGraphGetNodes(g->graph, nodes.data(), &n));
+  int k = 0;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    I8IE_HIP_TRY(hipGraphNodeGetType(nodes[i], &t));
+    if (t == hipGraphNodeTypeKernel) ++k;
+  }
+  if (kernel_nodes) *kernel_nodes = k;
+  if (all_nodes) *all_nodes = (int)n;
+  return I8IE_OK;
+}
+
+int i8ie_graph_destroy(i8ie_graph* g) {
+  if (!g) return I8IE_OK;
+  (void)hipStreamSynchronize(g->ctx->stream);  // no replay may still be reading the held blocks
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  for (void* b : g->held) (void)i8ie_free(g->ctx, b);
+  delete g;
+  return I8IE_OK;
+}
+
 }  // extern "C"
 
 int i8ie_ws_reserve(i8ie_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->ws_bytes) return I8IE_OK;
+  I8IE_REQUIRE(ctx->capture == nullptr, "workspace growth inside a graph capture: run the same calls once eagerly first");
   I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->ws) {
     I8IE_HIP_TRY(hipFree(ctx->ws));

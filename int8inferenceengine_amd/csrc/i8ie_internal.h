@@ -23,6 +23,7 @@ struct i8ie_ctx {
   unsigned prof_seen = 0;  // eligible launches since i8ie_profile_start
   hipStream_t copy_stream = nullptr;  // transfer stream for the *_async copies (created on first use)
   void* pinned = nullptr;  // std::unordered_map<void*, size_t>* of i8ie_host_malloc blocks
+  void* capture = nullptr;  // std::vector<void*>* while a graph is being captured: blocks freed meanwhile (i8ie_graph_*)
 };
 
 // Per-launch HIP-event timing on the ctx's stream (off unless i8ie_profile_start was

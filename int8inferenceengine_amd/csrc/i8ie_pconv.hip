@@ -56,6 +56,9 @@ struct PCArgs {
   float rcpOW, rcpCC1;
   int RT, bands, n_tiles;  // output rows per tile, tiles per image, tiles in all
   int P;                   // LDS pixel pitch (bytes) = C + 16
+  int row_gran;            // granules of a patch row in LDS: Wp (CC + 1) + pad, so that consecutive output pixels keep
+                           // walking the 16 slots of 256 B across the row wrap (row pitch / 16 = OW s P / 16 mod 16)
+  float rcpRowGran;
   int patch_gran;          // 16-byte granules of a full patch
   const int8_t* Bf;        // [pass][kt][ks][ntile][lane][16]
   unsigned bf_bytes;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   for (int i = tid; i < kTabPix; i += 512) {
     int oy, ox;
     pc_divmod(i < PT ? i : 0, p.OW, p.rcpOW, oy, ox);
-    reinterpret_cast<unsigned*>(smem + p.lds_tab)[i] = (unsigned)((oy * p.s) * p.Wp + ox * p.s) * (unsigned)p.P;
+    reinterpret_cast<unsigned*>(smem + p.lds_tab)[i] = (unsigned)(oy * p.s) * (unsigned)(p.row_gran * 16) + (unsigned)(ox * p.s) * (unsigned)p.P;
     reinterpret_cast<unsigned*>(smem + p.lds_tab)[kTabPix + i] = (unsigned)(oy * p.OWp + ox) * (unsigned)p.N;
   }
   for (int i = tid; i < p.nkt * 8; i += 512) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
     int tap, cc, kh, kw;
     pc_divmod(ci, p.CC, 1.0f / (float)p.CC, tap, cc);
     pc_divmod(tap, p.KW, 1.0f / (float)p.KW, kh, kw);
-    reinterpret_cast<unsigned*>(smem + p.lds_ktab)[i] = ci < p.kchunks ? (unsigned)(kh * p.Wp + kw) * (unsigned)p.P + (unsigned)cc * 16u : 0u;
+    reinterpret_cast<unsigned*>(smem + p.lds_ktab)[i] = ci < p.kchunks ? (unsigned)kh * (unsigned)(p.row_gran * 16) + (unsigned)kw * (unsigned)p.P + (unsigned)cc * 16u : 0u;
   }
   __syncthreads();
   // this lane's rows: tile (wm * TMW + mi), MFMA row lr -> pixel index inside the band
@@ -158,10 +161,11 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
     const int img = t / p.bands, band = t - img * p.bands;
     const unsigned src0 = (unsigned)img * p.img_pitch + (unsigned)(band * p.RT * p.s) * p.row_pitch;
     for (int g0 = 0; g0 < p.patch_gran; g0 += 512) {
-      const int g = g0 + tid;
-      int pix, ch;
-      pc_divmod(g, CC1, p.rcpCC1, pix, ch);
-      const unsigned so = src0 + (unsigned)pix * p.C + (unsigned)(ch < p.CC ? ch : 0) * 16u;  // (bounds: the descriptor)
+      int row, rem, pix, ch;
+      pc_divmod(g0 + tid, p.row_gran, p.rcpRowGran, row, rem);
+      pc_divmod(rem, CC1, p.rcpCC1, pix, ch);
+      if (pix >= p.Wp) pix = 0;  // (row padding: any readable bytes)
+      const unsigned so = src0 + (unsigned)row * p.row_pitch + (unsigned)pix * p.C + (unsigned)(ch < p.CC ? ch : 0) * 16u;  // (bounds: the descriptor)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(smem + dst + (g0 + wave * 64) * 16), 16,
                                                (int)so, 0, 0, 0);
     }
@@ -377,19 +381,49 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   // feature passes: 256 wide, or 192 wide when that divides N better (384 = 2 x 192)
   const int bn = (c.N % 256 == 0) ? 256 : (c.N % 192 == 0 ? 192 : 256);
   const int npass = (c.N + bn - 1) / bn;
-  // output rows per tile: as many whole rows as fit 256 pixels (16 MFMA row tiles)
-  int RT = 256 / c.OW;
-  if (RT < 1) return 0;
-  if (RT > c.OH) RT = c.OH;
+  // output rows per tile: whole rows, at most 256 pixels (16 MFMA row tiles), at least 129 (9 row tiles; smaller
+  // images go to the tiled kernel, which packs several of them into a tile).  Among those, the band height that
+  // needs the fewest (rounds over the CUs) x (row tiles per wave): 125 images of 27 x 27 are 375 bands of 9 rows
+  // (2 rounds of 8 row tiles) or 500 bands of 7 (2 rounds of 6)
+  static hipDeviceProp_t props[64];
+  static bool have[64] = {};
+  const int dev = ctx->device & 63;
+  if (!have[dev]) {
+    I8IE_HIP_TRY(hipGetDeviceProperties(&props[dev], ctx->device));
+    have[dev] = true;
+  }
+  int grid = props[dev].multiProcessorCount / 8 * 8;
+  if (grid < 8) grid = 8;
+  int RT = 0;
+  {
+    int rt_max = 256 / c.OW;
+    if (rt_max > c.OH) rt_max = c.OH;
+    double best = 0;
+    for (int rt = rt_max; rt >= 1; --rt) {
+      const int tm = (rt * c.OW + 15) / 16;
+      if (tm < 9) break;
+      const int bd = (c.OH + rt - 1) / rt;
+      long units = (long)n_img * bd;
+      if (units < grid && npass > 1) units *= npass;
+      const long rounds = (units + grid - 1) / grid;
+      const double cost = (double)rounds * ((tm <= 12 ? 6 : 8) + 1.5) * ((units < grid && npass > 1) ? 1 : npass);
+      if (RT == 0 || cost < best * 0.97) {
+        RT = rt;
+        best = cost;
+      }
+    }
+  }
+  if (RT == 0) return 0;
   const int bands = (c.OH + RT - 1) / RT;
   const int PT = RT * c.OW;
   const int TM = (PT + 15) / 16;
-  if (TM < 9) return 0;  // (small images: the tiled kernel packs several of them into a tile)
   const int TMW = TM <= 12 ? 6 : 8;
   const int CC = c.C / 16, Pp = c.C + 16;
   const int PR = (RT - 1) * c.sh + c.KH;
-  const int ppix = PR * c.Wp;
-  const int patch_gran = (ppix * (CC + 1) + 511) / 512 * 512;
+  const int m16 = Pp / 16;
+  const int row_pad = (((c.OW * c.sh - c.Wp) * m16) % 16 + 16) % 16;  // see PCArgs::row_gran
+  const int row_gran = c.Wp * (CC + 1) + row_pad;
+  const int patch_gran = (PR * row_gran + 511) / 512 * 512;
   const int kchunks = c.KH * c.KW * CC;
   const int nkt = (kchunks + 7) / 8;
   if (nkt < 2 || patch_gran >= (1 << 22)) return 0;
@@ -414,15 +448,6 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     *c.wcache = buf;
   }
 
-  static hipDeviceProp_t props[64];
-  static bool have[64] = {};
-  const int dev = ctx->device & 63;
-  if (!have[dev]) {
-    I8IE_HIP_TRY(hipGetDeviceProperties(&props[dev], ctx->device));
-    have[dev] = true;
-  }
-  int grid = props[dev].multiProcessorCount / 8 * 8;
-  if (grid < 8) grid = 8;
   // One block per CU walks whole bands: with fewer bands than CUs, the passes of a band become units of their own;
   // below 3/4 of the CUs even then, the tiled kernel (finer tiles, two blocks per CU) is the faster one (measured
   // at 125 images: conv3/conv4 0.028/0.038 ms tiled vs 0.035/0.048 ms here) unless the caller forces this kernel.
@@ -442,6 +467,8 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.RT = RT; a.bands = bands; a.n_tiles = n_img * bands;
   a.P = Pp;
   a.patch_gran = patch_gran;
+  a.row_gran = row_gran;
+  a.rcpRowGran = 1.0f / (float)row_gran;
   a.Bf = (const int8_t*)*c.wcache;
   a.bf_bytes = (unsigned)bf_bytes;
   a.nkt = nkt; a.kchunks = kchunks;

@@ -195,7 +195,6 @@ __global__ __launch_bounds__(512, 2) void pp_conv_kernel(PPArgs p) {
   };
   // weights: every CU streams the same panel once per tile and never re-reads a line, so they go around the L1
   // (sc1: served by L2 as usual) and leave it to the activation windows, whose K tiles overlap
-  v4i sinkv = {0, 0, 0, 0};
   auto dma_b = [&](const __amdgpu_buffer_rsrc_t& rs, int lds_off, unsigned voff, int soff) {
     if (DBG & 65536) {  // timing experiment: the same bytes as an ordinary load to VGPRs (no LDS write)
       const v4i v = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0));

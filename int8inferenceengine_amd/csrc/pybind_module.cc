@@ -1248,6 +1248,30 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
           auto [scale, zp] = cal.get_range(quantile);
           return py::make_tuple(scale, (int)zp);
         });
+  // ---- whole-forward replay as one HIP graph (include/i8ie_hip.h, i8ie_graph_*) ----------------------------
+  struct Graph {
+    i8ie_graph* g = nullptr;
+    ~Graph() { if (g) i8ie_graph_destroy(g); }
+  };
+  py::class_<Graph, std::shared_ptr<Graph>>(m, "Graph")
+      .def("launch", [](Graph& gr) { check(i8ie_graph_launch(gr.g)); })
+      .def("nodes", [](Graph& gr) {
+        int k = 0, n = 0;
+        check(i8ie_graph_nodes(gr.g, &k, &n));
+        return py::make_tuple(k, n);
+      });
+  m.def("graph_begin", []() { check(i8ie_graph_begin(ctx())); });
+  m.def("graph_end", []() {
+    auto gr = std::make_shared<Graph>();
+    check(i8ie_graph_end(ctx(), &gr->g));
+    return gr;
+  });
+  // overwrite a resident FP32 tensor's device buffer (the input a captured graph reads) from host memory
+  m.def("upload_into", [](Tensor<float>& t, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
+    if ((size_t)a.size() != (size_t)t.size) throw std::invalid_argument("upload_into: size mismatch");
+    check(i8ie_memcpy_h2d(ctx(), t.dptr(), a.data(), (size_t)t.size * 4));
+  });
+
   // raw device copy into / out of foreign HIP memory (e.g. a torch tensor's data_ptr) for the
   // multi-GPU logits gather; both sides must be used on this module's stream or synchronised.
   m.def("copy_to_ptr", [](Tensor<float>& t, uintptr_t dst) {
