@@ -158,6 +158,16 @@ int i8ie_maxpool2d_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, in
 int i8ie_relu_s8(i8ie_ctx* ctx, const int8_t* in_dev, int8_t* out_dev, int64_t n);
 int i8ie_maxpool2d_s8(i8ie_ctx* ctx, const int8_t* in_dev, int8_t* out_dev, int n, int c, int h, int w,
                       int kernel_size, int stride);
+/* Calibrator::sample  src/calibrator.cc:6-23 on the device, without copying the layer output to the host.
+ * The reference keeps 1000 samples: the first 1000 values seen fill the slots, every later value draws
+ * idx uniform in [0, 2000] from an UNSEEDED mt19937 (std::random_device) and overwrites slot idx when idx < 1000, so
+ * each slot ends up holding the last value that drew it.  Here the draw of global element number g is a
+ * counter-based hash of (seed, g): same distribution of slot contents, a different (and, unlike the reference's,
+ * reproducible) random stream.  `samples_dev` holds 1000 floats, `scratch_dev` 1000 ints; `seen_before` = values
+ * already sampled by earlier calls on this layer.  The host-side replay of the reference's own mt19937 stream
+ * (golden-pinned, tests/golden/ref_calibrator*.npz) stays in _CXX_i8ie for seeded runs. */
+int i8ie_calib_sample_f32(i8ie_ctx* ctx, const float* data_dev, int64_t n, int64_t seen_before, uint64_t seed,
+                          float* samples_dev, int* scratch_dev);
 /* down_scale  src/quantize_utils.cc:27-36 (standalone requantiser; the layers fuse it) */
 int i8ie_down_scale(i8ie_ctx* ctx, const int32_t* acc_dev, uint8_t* out_dev, int64_t n, float sa,
                     float sb, float sc, uint8_t zp_c);

@@ -150,6 +150,40 @@ __global__ __launch_bounds__(kThreads) void maxpool_s8_nchw_kernel(const int8_t*
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+
+// ---- Calibrator::sample on the device (src/calibrator.cc:6-23; include/i8ie_hip.h) ---------------------------
+constexpr int kCalibSlots = 1000;
+__device__ __forceinline__ uint32_t calib_draw(uint64_t seed, uint64_t g) {  // uniform in [0, 2000], splitmix64 of (seed, g)
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (g + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(((z >> 32) * 2001ull) >> 32);
+}
+// pass 1: the first 1000 values seen fill their slots; a later value that draws slot idx records its position
+// (the LAST one wins, as in the reference's sequential loop)
+__global__ __launch_bounds__(256) void calib_mark_kernel(const float* __restrict__ data, int64_t n, int64_t seen, uint64_t seed,
+                                                         float* __restrict__ samples, int* __restrict__ last) {
+  const int64_t gstride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gstride) {
+    const int64_t g = seen + i;
+    if (g < kCalibSlots) {
+      samples[g] = data[i];
+    } else {
+      const uint32_t idx = calib_draw(seed, (uint64_t)g);
+      if (idx < (uint32_t)kCalibSlots) atomicMax(&last[idx], (int)(i > 0x7FFFFFFF ? 0x7FFFFFFF : i));
+    }
+  }
+}
+__global__ __launch_bounds__(256) void calib_take_kernel(const float* __restrict__ data, float* __restrict__ samples,
+                                                         int* __restrict__ last) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < kCalibSlots) {
+    const int i = last[s];
+    if (i >= 0) samples[s] = data[i];
+    last[s] = -1;
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -217,6 +251,22 @@ int i8ie_maxpool2d_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int n, int
   I8ieProfScope prof(ctx, "maxpool_u8_nchw", 0.0, (double)n * c * h * w + (double)total);
   maxpool_u8_nchw_kernel<<<grid_for(total), kThreads, 0, ctx->stream>>>(in, out, total, h, w, oh, ow,
                                                                        k, s);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+int i8ie_calib_sample_f32(i8ie_ctx* ctx, const float* data, int64_t n, int64_t seen_before, uint64_t seed, float* samples,
+                          int* scratch) {
+  I8IE_REQUIRE(ctx && data && samples && scratch, "null argument");
+  I8IE_REQUIRE(n >= 0 && seen_before >= 0, "negative size");
+  I8IE_REQUIRE(n <= 0x7FFFFFFF, "one call samples at most 2^31 - 1 values");
+  if (n == 0) return I8IE_OK;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  if (seen_before == 0) I8IE_HIP_TRY(hipMemsetAsync(scratch, 0xFF, kCalibSlots * sizeof(int), ctx->stream));  // all -1
+  I8ieProfScope prof(ctx, "calib_sample", 0.0, 4.0 * n);
+  calib_mark_kernel<<<grid_for(n), kThreads, 0, ctx->stream>>>(data, n, seen_before, seed, samples, scratch);
+  I8IE_LAUNCH_CHECK();
+  calib_take_kernel<<<(kCalibSlots + 255) / 256, 256, 0, ctx->stream>>>(data, samples, scratch);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <unordered_map>
 #include <type_traits>
 #include <vector>
 
@@ -62,7 +63,8 @@ struct PCArgs {
   int patch_gran;          // 16-byte granules of a full patch
   const int8_t* Bf;        // [pass][kt][ks][ntile][lane][16]
   unsigned bf_bytes;
-  int nkt, kchunks;        // K tiles of 8 chunks; valid 16-byte chunks of K
+  int nkt;                 // K tiles of 8 chunks
+  const int* perm;         // [nkt * 8]: source chunk (tap * CC + channel chunk) of K position ci, -1 = zero padding
   int N, npass;
   const int32_t* ocp;
   int Npad;
@@ -73,7 +75,7 @@ struct PCArgs {
   int ob, OHp, OWp;
   int lds_patch, lds_ocp, lds_tab, lds_ktab;  // LDS offsets
   int split;                // 1: a (band, feature pass) pair is a unit of its own (small batches: more units than CUs)
-  int flags;                // experiment (variant 53): 1 = weights of the next pass fetched by the last K tile
+  int flags;                // 1 = weights of the next pass fetched by the last K tile (not with split)
   unsigned long long* dbg;  // variant 51: per block, cycles spent per phase (wave 0)
 };
 
@@ -138,11 +140,12 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
     reinterpret_cast<unsigned*>(smem + p.lds_tab)[kTabPix + i] = (unsigned)(oy * p.OWp + ox) * (unsigned)p.N;
   }
   for (int i = tid; i < p.nkt * 8; i += 512) {
-    const int ci = 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1);
+    const int ci = 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1);  // K position of (K tile i / 8, k-step (i / 4) & 1, lane group i & 3)
+    const int sc = p.perm[ci];
     int tap, cc, kh, kw;
-    pc_divmod(ci, p.CC, 1.0f / (float)p.CC, tap, cc);
+    pc_divmod(sc < 0 ? 0 : sc, p.CC, 1.0f / (float)p.CC, tap, cc);
     pc_divmod(tap, p.KW, 1.0f / (float)p.KW, kh, kw);
-    reinterpret_cast<unsigned*>(smem + p.lds_ktab)[i] = ci < p.kchunks ? (unsigned)kh * (unsigned)(p.row_gran * 16) + (unsigned)kw * (unsigned)p.P + (unsigned)cc * 16u : 0u;
+    reinterpret_cast<unsigned*>(smem + p.lds_ktab)[i] = sc >= 0 ? (unsigned)kh * (unsigned)(p.row_gran * 16) + (unsigned)kw * (unsigned)p.P + (unsigned)cc * 16u : 0u;
   }
   __syncthreads();
   // this lane's rows: tile (wm * TMW + mi), MFMA row lr -> pixel index inside the band
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   };
   const int lin_total = p.npass * p.nkt;
   const int patch = p.lds_patch;
-  const bool xpre = (p.flags & 1) != 0;  // experiment: the last K tile of a pass already fetches the next pass's weights
+  const bool xpre = (p.flags & 1) != 0;  // the last K tile of a pass already fetches the first weights of the next pass / band (+1 %)
   auto tile_of = [&](int u) { return p.split ? u / p.npass : u; };
   patch_fill(tile_of(unit), patch);
   pc_wait_vm<0>();
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
 
 // ---- weights in fragment order for this kernel's K walk: [pass][kt][ks][ntile][lane][16] --------------------
 __global__ __launch_bounds__(256) void pconv_pack_kernel(const int8_t* __restrict__ B, int8_t* __restrict__ Bf, int64_t total16,
-                                                         int Kpad, int Npad, int kchunks, int nkt, int bn) {
+                                                         int Kpad, int Npad, const int* __restrict__ perm, int nkt, int bn) {
   const int nt = bn / 16;
   const int64_t gstride = (int64_t)gridDim.x * 256;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total16; e += gstride) {
@@ -347,10 +350,10 @@ __global__ __launch_bounds__(256) void pconv_pack_kernel(const int8_t* __restric
     const int kt = (int)(t % nkt);
     const int pass = (int)(t / nkt);
     const int q = lane >> 4, r = lane & 15;
-    const int chunk = 8 * kt + 2 * q + ks;
+    const int chunk = perm[8 * kt + 2 * q + ks];
     const int n = pass * bn + ntile * 16 + r;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (chunk < kchunks && chunk * 16 < Kpad && n < Npad) v = *reinterpret_cast<const uint4*>(B + (size_t)n * Kpad + (size_t)chunk * 16);
+    if (chunk >= 0 && chunk * 16 < Kpad && n < Npad) v = *reinterpret_cast<const uint4*>(B + (size_t)n * Kpad + (size_t)chunk * 16);
     reinterpret_cast<uint4*>(Bf)[e] = v;
   }
 }
@@ -424,8 +427,36 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   const int row_pad = (((c.OW * c.sh - c.Wp) * m16) % 16 + 16) % 16;  // see PCArgs::row_gran
   const int row_gran = c.Wp * (CC + 1) + row_pad;
   const int patch_gran = (PR * row_gran + 511) / 512 * 512;
+  // K order: the lanes one ds_read_b128 cycle serves come from two lane groups (q, q + 1), which read the K chunks at
+  // positions ci and ci + 2 of a K tile.  Their 256-byte slots stay disjoint when the two chunks' LDS offsets
+  // have the same parity in 16-byte units (even pixels + even offset vs odd pixels + even offset).  Pair the
+  // chunks accordingly: with 96 channels (6 chunks per tap) the natural order pairs chunks of different taps,
+  // an odd distance apart, a third of the time (PMC: 24 % of LDS-active cycles were bank conflicts on conv2).
   const int kchunks = c.KH * c.KW * CC;
-  const int nkt = (kchunks + 7) / 8;
+  const int row_par = (c.OW * c.sh) & 1;  // parity of the LDS row pitch / 16 (see PCArgs::row_gran; P / 16 is odd)
+  std::vector<int> perm;
+  {
+    std::vector<int> cls[2];
+    for (int sc = 0; sc < kchunks; ++sc) {
+      const int tap = sc / CC, cc = sc - tap * CC, kh = tap / c.KW, kw = tap - kh * c.KW;
+      cls[(kh * row_par + kw + cc) & 1].push_back(sc);
+    }
+    std::vector<int> pairs;  // two entries per pair
+    for (int par = 0; par < 2; ++par)
+      for (size_t i = 0; i < cls[par].size(); i += 2) {
+        pairs.push_back(cls[par][i]);
+        pairs.push_back(i + 1 < cls[par].size() ? cls[par][i + 1] : -1);
+      }
+    const int npairs = (int)pairs.size() / 2;
+    const int nkt_ = (npairs + 3) / 4;
+    perm.assign((size_t)nkt_ * 8, -1);
+    for (int j = 0; j < npairs; ++j) {  // pair j of K tile kt: (q, k-step) = (0|1, 0), (0|1, 1), (2|3, 0), (2|3, 1)
+      const int kt = j >> 2, w = j & 3, base = 8 * kt + (w >> 1) * 4 + (w & 1);
+      perm[base] = pairs[2 * j];
+      perm[base + 2] = pairs[2 * j + 1];
+    }
+  }
+  const int nkt = (int)perm.size() / 8;
   if (nkt < 2 || patch_gran >= (1 << 22)) return 0;
   const size_t out_pixels = (size_t)n_img * (c.OH + 2 * c.ob) * (c.OW + 2 * c.ob);
   const size_t out_bytes = out_pixels * (size_t)c.N;
@@ -436,16 +467,26 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   if (patch_gran * 16 + fixed > 160 * 1024) return 0;
 
   // ---- fragment-packed weights (once per layer: the slot lives in the layer handle)
+  // (the slot holds [perm: nkt * 8 ints, padded to 256 B][weights]; re-packed when the pairing key changes)
+  const size_t perm_bytes = i8ie_align_up((size_t)nkt * 8 * sizeof(int), 256);
   const size_t bf_bytes = (size_t)npass * nkt * kt_bytes;
-  if (*c.wcache == nullptr) {
-    void* buf = nullptr;
-    I8IE_TRY(i8ie_malloc(ctx, bf_bytes, &buf));
-    const int64_t total16 = (int64_t)(bf_bytes / 16);
-    int64_t blocks = (total16 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    pconv_pack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.B, (int8_t*)buf, total16, c.Kpad, c.Npad, kchunks, nkt, bn);
-    I8IE_LAUNCH_CHECK();
-    *c.wcache = buf;
+  {
+    static std::mutex mu;
+    static std::unordered_map<void*, int> key_of;
+    std::lock_guard<std::mutex> lock(mu);
+    const int key = row_par | (bn << 1);
+    if (*c.wcache == nullptr || key_of[*c.wcache] != key) {
+      void* buf = *c.wcache;
+      if (buf == nullptr) I8IE_TRY(i8ie_malloc(ctx, perm_bytes + bf_bytes, &buf));
+      I8IE_TRY(i8ie_memcpy_h2d(ctx, buf, perm.data(), perm.size() * sizeof(int)));
+      const int64_t total16 = (int64_t)(bf_bytes / 16);
+      int64_t blocks = (total16 + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      pconv_pack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.B, (int8_t*)buf + perm_bytes, total16, c.Kpad, c.Npad, (const int*)buf, nkt, bn);
+      I8IE_LAUNCH_CHECK();
+      *c.wcache = buf;
+      key_of[buf] = key;
+    }
   }
 
   // One block per CU walks whole bands: with fewer bands than CUs, the passes of a band become units of their own;
@@ -469,9 +510,10 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.patch_gran = patch_gran;
   a.row_gran = row_gran;
   a.rcpRowGran = 1.0f / (float)row_gran;
-  a.Bf = (const int8_t*)*c.wcache;
+  a.Bf = (const int8_t*)*c.wcache + perm_bytes;
+  a.perm = (const int*)*c.wcache;
   a.bf_bytes = (unsigned)bf_bytes;
-  a.nkt = nkt; a.kchunks = kchunks;
+  a.nkt = nkt;
   a.N = c.N; a.npass = npass;
   a.ocp = c.ocp; a.Npad = c.Npad;
   a.rq = i8ie_make_requant(c.s_in, c.s_w, c.s_out, c.zp_out);
@@ -480,7 +522,7 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.out_bytes = (unsigned)out_bytes;
   a.ob = c.ob; a.OHp = c.OH + 2 * c.ob; a.OWp = c.OW + 2 * c.ob;
   a.split = split;
-  a.flags = (ctx->variant == 53 && !split) ? 1 : 0;
+  a.flags = (ctx->variant != 53 && !split) ? 1 : 0;  // (variant 53: weights fetched at the start of every pass)
   a.lds_patch = 0;
   a.lds_ocp = patch_gran * 16;
   a.lds_tab = a.lds_ocp + npass * bn * 4;

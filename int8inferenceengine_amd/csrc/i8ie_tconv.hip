@@ -25,6 +25,8 @@
 // Results are those of the other contraction kernels bit for bit (same exact integer sums, same requantiser).
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "i8ie_calls.h"
@@ -50,6 +52,11 @@ struct TCArgs {
   int CCs, Ps;             // 16-byte chunks per pixel of a slice; LDS pixel pitch of a slice (bytes) = 16 CCs + 16
   float rcpCCs1;
   int slice_gran;          // 16-byte granules of a ring buffer (multiple of 512)
+  int row_gran;            // granules of a slice row in LDS: Wp (CCs + 1) + pad, so that consecutive output pixels keep
+                           // walking the 16 slots of 256 B across the row wrap (as in i8ie_pconv.hip)
+  float rcpRowGran;
+  const int* perm;         // S == 1: [nkt * 8] source chunk of K position ci (-1 = zero padding), pairs of equal LDS
+                           // slot parity (i8ie_pconv.hip); null: natural (slice, tap, chunk) order
   int Ks, Ksp;             // K chunks of a slice: valid, padded to whole K tiles
   const int8_t* Bf;        // [pass][kt][ks][feature tile][lane][16]
   unsigned bf_bytes;
@@ -124,17 +131,25 @@ __global__ __launch_bounds__(512, 2) void tconv_kernel(TCArgs p) {
   for (int i = tid; i < kTabPix; i += 512) {
     int oy, ox;
     tc_divmod(i < PT ? i : 0, p.OW, p.rcpOW, oy, ox);
-    reinterpret_cast<unsigned*>(smem + p.lds_tab)[i] = (unsigned)((oy * p.s) * p.Wp + ox * p.s) * (unsigned)p.Ps;
+    reinterpret_cast<unsigned*>(smem + p.lds_tab)[i] = (unsigned)(oy * p.s) * (unsigned)(p.row_gran * 16) + (unsigned)(ox * p.s) * (unsigned)p.Ps;
     reinterpret_cast<unsigned*>(smem + p.lds_tab)[kTabPix + i] = (unsigned)(oy * p.OWp + ox) * (unsigned)p.N;
   }
   for (int i = tid; i < p.nkt * 8; i += 512) {
     const int ci = 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1);  // chunk of (K tile i / 8, k-step (i / 4) & 1, lane group i & 3)
-    const int sl = ci >= p.Ksp ? 1 : 0;                          // (S == 1: Ksp covers all of K)
-    const int r = ci - sl * p.Ksp;
+    int r = ci, ok;
+    if (p.perm != nullptr) {
+      r = p.perm[ci];
+      ok = r >= 0;
+      if (!ok) r = 0;
+    } else {
+      const int sl = ci >= p.Ksp ? 1 : 0;  // (natural order: slice-major, each slice padded to whole K tiles)
+      r = ci - sl * p.Ksp;
+      ok = r < p.Ks;
+    }
     int tap, cc, kh, kw;
     tc_divmod(r, p.CCs, 1.0f / (float)p.CCs, tap, cc);
     tc_divmod(tap, p.KW, 1.0f / (float)p.KW, kh, kw);
-    reinterpret_cast<unsigned*>(smem + p.lds_ktab)[i] = r < p.Ks ? (unsigned)(kh * p.Wp + kw) * (unsigned)p.Ps + (unsigned)cc * 16u : 0u;
+    reinterpret_cast<unsigned*>(smem + p.lds_ktab)[i] = ok ? (unsigned)kh * (unsigned)(p.row_gran * 16) + (unsigned)kw * (unsigned)p.Ps + (unsigned)cc * 16u : 0u;
   }
   __syncthreads();
   const int pix0 = tm * TMW * 16 + tc_row_to_pix(lr);
@@ -156,9 +171,11 @@ __global__ __launch_bounds__(512, 2) void tconv_kernel(TCArgs p) {
     const unsigned src0 = (unsigned)img * p.img_pitch + (unsigned)(band * p.RT * p.s) * p.row_pitch + (unsigned)(sl * p.CCs * 16);
     const int dst = ring_of(j * p.S + sl);
     for (int g0 = 0; g0 < p.slice_gran; g0 += 512) {
-      int pix, ch;
-      tc_divmod(g0 + tid, CCs1, p.rcpCCs1, pix, ch);
-      const unsigned so = src0 + (unsigned)pix * p.C + (unsigned)(ch < p.CCs ? ch : 0) * 16u;  // (bounds: the descriptor)
+      int row, rem, pix, ch;
+      tc_divmod(g0 + tid, p.row_gran, p.rcpRowGran, row, rem);
+      tc_divmod(rem, CCs1, p.rcpCCs1, pix, ch);
+      if (pix >= p.Wp) pix = 0;  // (row padding: any readable bytes)
+      const unsigned so = src0 + (unsigned)row * p.row_pitch + (unsigned)pix * p.C + (unsigned)(ch < p.CCs ? ch : 0) * 16u;  // (bounds: the descriptor)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(smem + dst + (g0 + wave * 64) * 16), 16, (int)so, 0, 0, 0);
     }
   };
@@ -334,7 +351,8 @@ __global__ __launch_bounds__(512, 2) void tconv_kernel(TCArgs p) {
 // ---- weights in fragment order for this kernel's K walk: [pass][kt][ks][ntile][lane][16]; K is ordered
 //      (channel slice, tap, channel chunk of the slice), each slice padded with zeros to whole K tiles ----------
 __global__ __launch_bounds__(256) void tconv_pack_kernel(const int8_t* __restrict__ B, int8_t* __restrict__ Bf, int64_t total16,
-                                                         int Kpad, int Npad, int CC, int CCs, int Ks, int Ksp, int S, int nkt, int bn) {
+                                                         int Kpad, int Npad, int CC, int CCs, int Ks, int Ksp, int S, int nkt, int bn,
+                                                         const int* __restrict__ perm) {
   const int nt = bn / 16;
   const int64_t gstride = (int64_t)gridDim.x * 256;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total16; e += gstride) {
@@ -348,8 +366,12 @@ __global__ __launch_bounds__(256) void tconv_pack_kernel(const int8_t* __restric
     const int pass = (int)(t / nkt);
     const int q = lane >> 4, r = lane & 15;
     const int ci = 8 * kt + 2 * q + ks;
-    const int sl = ci >= Ksp ? 1 : 0;
-    const int rr = ci - sl * Ksp;
+    int sl = ci >= Ksp ? 1 : 0;
+    int rr = ci - sl * Ksp;
+    if (perm != nullptr) {
+      sl = 0;
+      rr = perm[ci] >= 0 ? perm[ci] : Ks;
+    }
     const int n = pass * bn + ntile * 16 + r;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (rr < Ks && sl < S && n < Npad) {
@@ -397,24 +419,66 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   const int TMW = TM <= 12 ? 6 : 8;
   const int CC = c.C / 16;
   const int PR = (RT - 1) * c.sh + c.KH;
-  const int ppix = PR * c.Wp;
   const int taps = c.KH * c.KW;
   // patch ring: whole patches in two buffers if they fit, else two channel slices per patch in three buffers
   const int fixed = npass * bn * 4 + 2 * kTabPix * 4;
   int S = 1, R = 2, CCs = CC, slice_gran = 0, Ks = 0, Ksp = 0, nkt = 0, kt_split = 0;
+  const int row_par = (c.OW * c.sh) & 1;
+  int row_gran = 0;
+  std::vector<int> perm;  // S == 1 only
   auto plan = [&](int S_, int R_) {
     S = S_; R = R_;
     CCs = CC / S;
-    slice_gran = (ppix * (CCs + 1) + 511) / 512 * 512;
+    const int m16 = CCs + 1;  // slice pixel pitch / 16 (odd: CCs is even)
+    const int row_pad = (((c.OW * c.sh - c.Wp) * m16) % 16 + 16) % 16;
+    row_gran = c.Wp * (CCs + 1) + row_pad;
+    slice_gran = (PR * row_gran + 511) / 512 * 512;
     Ks = taps * CCs;
-    Ksp = (Ks + 7) / 8 * 8;
-    nkt = S * Ksp / 8;
+    perm.clear();
+    if (S == 1) {  // pairs of equal LDS slot parity (i8ie_pconv.hip)
+      std::vector<int> cls[2];
+      for (int sc = 0; sc < Ks; ++sc) {
+        const int tap = sc / CCs, cc = sc - tap * CCs, kh = tap / c.KW, kw = tap - kh * c.KW;
+        cls[(kh * row_par + kw + cc) & 1].push_back(sc);
+      }
+      std::vector<int> pairs;
+      for (int par = 0; par < 2; ++par)
+        for (size_t i = 0; i < cls[par].size(); i += 2) {
+          pairs.push_back(cls[par][i]);
+          pairs.push_back(i + 1 < cls[par].size() ? cls[par][i + 1] : -1);
+        }
+      const int npairs = (int)pairs.size() / 2;
+      nkt = (npairs + 3) / 4;
+      perm.assign((size_t)nkt * 8, -1);
+      for (int j = 0; j < npairs; ++j) {
+        const int kt = j >> 2, w = j & 3, base = 8 * kt + (w >> 1) * 4 + (w & 1);
+        perm[base] = pairs[2 * j];
+        perm[base + 2] = pairs[2 * j + 1];
+      }
+      Ksp = nkt * 8;
+    } else {
+      Ksp = (Ks + 7) / 8 * 8;
+      nkt = S * Ksp / 8;
+    }
     return R * slice_gran * 16 + fixed + nkt * 32 <= 160 * 1024;
   };
   if (!plan(1, 2)) {
-    if (CC % 4 != 0 || !plan(2, 3)) return 0;  // (slices keep an even chunk count: the bank scheme needs pitch / 16 odd)
+    if (CC % 4 != 0 || !plan(2, 3)) return 0;  // (slices keep a chunk count that is a multiple of 4: natural K order pairs well)
   }
   if (nkt < 4 || slice_gran >= (1 << 22)) return 0;
+  static hipDeviceProp_t props[64];
+  static bool have[64] = {};
+  const int dev = ctx->device & 63;
+  if (!have[dev]) {
+    I8IE_HIP_TRY(hipGetDeviceProperties(&props[dev], ctx->device));
+    have[dev] = true;
+  }
+  int grid = props[dev].multiProcessorCount / 8 * 8;
+  if (grid < 8) grid = 8;
+  // Chosen automatically only where it measured faster than i8ie_pconv.hip: one feature pass, whole patches in the
+  // ring, and enough bands per CU to amortise the idle first / last segment of the two teams (AlexNet conv2 at
+  // 1000 images: 3000 bands, 2360 vs 2280 TOP/s); variant 70 forces it.
+  if (ctx->variant == 0 && !(npass == 1 && S == 1 && (long)n_img * bands >= 8L * grid)) return 0;
   if (S == 2) {
     kt_split = Ksp / 8;
   } else {
@@ -429,16 +493,27 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
 
   // ---- fragment-packed weights (once per layer: the slot lives in the layer handle)
   const int kt_bytes = bn * 128;
+  // (the slot holds [perm: nkt * 8 ints, padded to 256 B][weights]; re-packed when the pairing key changes)
+  const size_t perm_bytes = i8ie_align_up((size_t)nkt * 8 * sizeof(int), 256);
   const size_t bf_bytes = (size_t)npass * nkt * kt_bytes;
-  if (*c.wcache2 == nullptr) {
-    void* buf = nullptr;
-    I8IE_TRY(i8ie_malloc(ctx, bf_bytes, &buf));
-    const int64_t total16 = (int64_t)(bf_bytes / 16);
-    int64_t blocks = (total16 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    tconv_pack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.B, (int8_t*)buf, total16, c.Kpad, c.Npad, CC, CCs, Ks, Ksp, S, nkt, bn);
-    I8IE_LAUNCH_CHECK();
-    *c.wcache2 = buf;
+  {
+    static std::mutex mu;
+    static std::unordered_map<void*, int> key_of;
+    std::lock_guard<std::mutex> lock(mu);
+    const int key = row_par | (S << 1) | (bn << 4);
+    if (*c.wcache2 == nullptr || key_of[*c.wcache2] != key) {
+      void* buf = *c.wcache2;
+      if (buf == nullptr) I8IE_TRY(i8ie_malloc(ctx, perm_bytes + bf_bytes, &buf));
+      if (!perm.empty()) I8IE_TRY(i8ie_memcpy_h2d(ctx, buf, perm.data(), perm.size() * sizeof(int)));
+      const int64_t total16 = (int64_t)(bf_bytes / 16);
+      int64_t blocks = (total16 + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      tconv_pack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.B, (int8_t*)buf + perm_bytes, total16, c.Kpad, c.Npad, CC, CCs, Ks, Ksp, S, nkt, bn,
+                                                               perm.empty() ? nullptr : (const int*)buf);
+      I8IE_LAUNCH_CHECK();
+      *c.wcache2 = buf;
+      key_of[buf] = key;
+    }
   }
 
   TCArgs a{};
@@ -453,8 +528,11 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.S = S; a.R = R; a.CCs = CCs; a.Ps = CCs * 16 + 16;
   a.rcpCCs1 = 1.0f / (float)(CCs + 1);
   a.slice_gran = slice_gran;
+  a.row_gran = row_gran;
+  a.rcpRowGran = 1.0f / (float)row_gran;
+  a.perm = perm.empty() ? nullptr : (const int*)*c.wcache2;
   a.Ks = Ks; a.Ksp = S == 2 ? Ksp : nkt * 8;
-  a.Bf = (const int8_t*)*c.wcache2;
+  a.Bf = (const int8_t*)*c.wcache2 + perm_bytes;
   a.bf_bytes = (unsigned)bf_bytes;
   a.nkt = nkt; a.kt_split = kt_split;
   a.N = c.N; a.npass = npass;
@@ -473,15 +551,6 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   if (ctx->variant == 73) a.flags = 2;
   if (ctx->variant == 74) a.flags = 3;
 
-  static hipDeviceProp_t props[64];
-  static bool have[64] = {};
-  const int dev = ctx->device & 63;
-  if (!have[dev]) {
-    I8IE_HIP_TRY(hipGetDeviceProperties(&props[dev], ctx->device));
-    have[dev] = true;
-  }
-  int grid = props[dev].multiProcessorCount / 8 * 8;
-  if (grid < 8) grid = 8;
   const double ops = 2.0 * c.M * c.N * c.Ktrue;
   const double bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
   char tag[64];

@@ -47,6 +47,8 @@ struct Runtime {
   i8ie_ctx* ctx = nullptr;
   int device = -1;
   long calib_seed = -1;  // < 0: std::random_device, as the reference (src/calibrator.cc:9-10)
+  int calib_mode = 0;    // 0 auto: seeded -> the reference's mt19937 stream replayed on the host (golden-pinned),
+                         // unseeded -> sampled on the device (no D2H of the layer outputs); 1 host; 2 device
 };
 Runtime& rt() {
   static Runtime* r = new Runtime();  // intentionally leaked: outlives every tensor at exit
@@ -701,6 +703,35 @@ constexpr ssize_t kNumSamples = 1000;
 struct Calibrator {
   std::array<float, kNumSamples> samples{};  // value-initialised (make_unique<Calibrator>(), src/layer.cc:33)
   ssize_t cnt = 0;
+  // device-side sampling (i8ie_calib_sample_f32): the 1000 slots live on the GPU until get_range()
+  float* samples_dev = nullptr;
+  int* scratch_dev = nullptr;
+  int64_t seen = 0;
+  uint64_t dev_seed = 0;
+  Calibrator() = default;
+  Calibrator(const Calibrator&) = delete;
+  Calibrator& operator=(const Calibrator&) = delete;
+  ~Calibrator() {
+    if (samples_dev) i8ie_free(rt().ctx, samples_dev);
+    if (scratch_dev) i8ie_free(rt().ctx, scratch_dev);
+  }
+  static bool on_device() { return rt().calib_mode == 2 || (rt().calib_mode == 0 && rt().calib_seed < 0); }
+  void sample_device(const float* dptr, ssize_t n) {
+    if (!samples_dev) {
+      check(i8ie_malloc(rt().ctx, kNumSamples * sizeof(float), (void**)&samples_dev));
+      check(i8ie_malloc(rt().ctx, kNumSamples * sizeof(int), (void**)&scratch_dev));
+      check(i8ie_memset(rt().ctx, samples_dev, 0, kNumSamples * sizeof(float)));
+      if (rt().calib_seed >= 0) {
+        dev_seed = (uint64_t)rt().calib_seed;
+      } else {
+        std::random_device rd;
+        dev_seed = ((uint64_t)rd() << 32) | rd();
+      }
+    }
+    check(i8ie_calib_sample_f32(rt().ctx, dptr, (int64_t)n, seen, dev_seed, samples_dev, scratch_dev));
+    seen += n;
+    cnt = seen < kNumSamples ? (ssize_t)seen : kNumSamples;
+  }
   void sample(const float* data, ssize_t n) {
     std::mt19937 rng;
     if (rt().calib_seed >= 0) {
@@ -720,6 +751,7 @@ struct Calibrator {
     }
   }
   std::tuple<float, u8_t> get_range(float quantile) {
+    if (samples_dev) check(i8ie_memcpy_d2h(rt().ctx, samples.data(), samples_dev, kNumSamples * sizeof(float)));
     std::sort(samples.begin(), samples.end());
     float out_min = samples[(size_t)((1.0 - quantile) * cnt)];
     float out_max = samples[(size_t)(quantile * (cnt - 1))];
@@ -969,6 +1001,10 @@ class BaseLayer {
   }
   void maybe_sample(Tensor<float>& out) {  // src/conv2d.cc:94-96, src/fully_connected.cc:17-19
     if (!is_preparing_) return;
+    if (Calibrator::on_device()) {  // no copy of the layer output to the host
+      cal_->sample_device(out.dptr(), out.size);
+      return;
+    }
     py::array_t<float> a = out.numpy();
     cal_->sample(a.data(), out.size);
   }
@@ -1240,6 +1276,41 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
     check(i8ie_ctx_create_on_stream(device, (void*)stream, &rt().ctx));
   });
   m.def("set_calibration_seed", [](long seed) { rt().calib_seed = seed; });
+  // where Calibrator::sample runs: "auto" (seeded: host replay of the reference's mt19937 stream; unseeded: on the
+  // device), "host", "device" (seeded or not: counter-based draws, reproducible for a given seed)
+  m.def("set_calibration_mode", [](const std::string& mode) {
+    if (mode == "auto") rt().calib_mode = 0;
+    else if (mode == "host") rt().calib_mode = 1;
+    else if (mode == "device") rt().calib_mode = 2;
+    else throw std::invalid_argument("set_calibration_mode: auto | host | device");
+  });
+  m.def("calibration_mode", []() { return std::string(rt().calib_mode == 0 ? "auto" : rt().calib_mode == 1 ? "host" : "device"); });
+  // the device sampler on its own: feed chunks (device tensors), then the 1000 slots and get_range()
+  m.def("calibrator_device_samples", [](std::vector<py::array_t<float, py::array::c_style | py::array::forcecast>> chunks, long seed) {
+    const long keep_seed = rt().calib_seed;
+    rt().calib_seed = seed;
+    Calibrator cal;
+    try {
+      for (auto& c : chunks) {
+        float* d = nullptr;
+        check(i8ie_malloc(ctx(), (size_t)c.size() * 4 + 4, (void**)&d));
+        check(i8ie_memcpy_h2d(ctx(), d, c.data(), (size_t)c.size() * 4));
+        cal.sample_device(d, (ssize_t)c.size());
+        check(i8ie_sync(ctx()));
+        i8ie_free(ctx(), d);
+      }
+    } catch (...) {
+      rt().calib_seed = keep_seed;
+      throw;
+    }
+    rt().calib_seed = keep_seed;
+    py::array_t<float> slots(kNumSamples);
+    check(i8ie_memcpy_d2h(ctx(), slots.mutable_data(), cal.samples_dev, kNumSamples * sizeof(float)));
+    float s;
+    u8_t z;
+    std::tie(s, z) = cal.get_range(1);
+    return py::make_tuple(slots, (long)cal.cnt, s, (int)z);
+  });
   // the layers' calibrator on its own (host code, no GPU): feed chunks through sample(), then get_range()
   m.def("calibrator_range",
         [](std::vector<py::array_t<float, py::array::c_style | py::array::forcecast>> chunks, float quantile) {

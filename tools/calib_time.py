@@ -5,6 +5,9 @@ import int8inferenceengine_amd, i8ie, _CXX_i8ie as cx
 from int8inferenceengine_amd import workloads as wl
 sd = wl.synthetic_state_dict("alexnet", seed=42)
 x = wl.synthetic_input("alexnet", 100, seed=7)
+mode = sys.argv[1] if len(sys.argv) > 1 else "device"
+cx.set_calibration_mode(mode)
+print("calibration sampler:", mode)
 for rep in range(3):
     net = wl.build("alexnet"); net.load(sd)
     xt = i8ie.tensor(x).prefetch(); cx.synchronize()
