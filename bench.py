@@ -88,7 +88,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
-        # run our kernels on torch's current stream so the collective is stream-ordered behind them
+        # run our kernels on torch's current stream so the collective is stream-ordered behind them; a stream of
+        # its own rather than the legacy default stream (which cannot be captured into a HIP graph and serialises
+        # with every blocking stream)
+        torch.cuda.set_stream(torch.cuda.Stream())
         cx.use_stream(torch.cuda.current_stream().cuda_stream, local_rank)
     else:
         cx.set_device(local_rank)

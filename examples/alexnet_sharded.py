@@ -40,6 +40,7 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29555")
     dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
+    torch.cuda.set_stream(torch.cuda.Stream())  # not the legacy default stream (no graph capture there, implicit syncs)
     cx.use_stream(torch.cuda.current_stream().cuda_stream, local_rank)  # engine kernels on torch's stream
 
     net = wl.calibrated("alexnet", wl.synthetic_state_dict("alexnet"))  # identical on every rank (seeded)

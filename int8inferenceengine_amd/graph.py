@@ -10,6 +10,8 @@ Python + pybind dispatch.  `GraphedForward` records the launches of one `forward
     y = g()                          # replay; y is always the same device tensor, overwritten by every replay
     g.load(next_batch)               # new input values into the captured input buffer (same shape)
 
+The ctx must run on a stream of its own (the default after `import i8ie`; when borrowing torch's stream with
+`use_stream`, make a `torch.cuda.Stream()` current first: the legacy default stream cannot be captured).
 Everything the forward needs lazily (workspace, re-packed weights, offset vectors) is created by the eager run;
 a forward whose launches depend on host-side values that change from call to call cannot be captured.
 """

@@ -70,7 +70,9 @@ class ShardedRunner:
       tensor on the GPU.  Its logits are copied into one of two stage buffers on the compute stream; the all-gather
       and rank 0's copy to pinned host memory run on a SIDE stream behind an event, so the collective's latency and
       the wait for the slowest rank overlap the next batch's kernels.  A stage buffer is reused only after the
-      gather that read it has signalled.  Call `_CXX_i8ie.use_stream(torch.cuda.current_stream().cuda_stream, dev)`
+      gather that read it has signalled.  Make a `torch.cuda.Stream()` current (not the legacy default stream: it
+      cannot be captured into a HIP graph and serialises with blocking streams) and call
+      `_CXX_i8ie.use_stream(torch.cuda.current_stream().cuda_stream, dev)`
       before the first op so that the engine's kernels and these copies share torch's stream.
     * host mode (`host_copies=True`; backend "gloo"): `forward(x)` returns an ndarray (or an `i8ie` tensor that is
       read back); the gather runs on CPU tensors.  This is what the CPU tests and the one-GPU rehearsal use (RCCL
