@@ -381,10 +381,10 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   const int P = c.OH * c.OW;
   const int n_img = c.M / P;
   if (n_img * P != c.M || n_img < 64) return 0;  // whole images, and enough of them to fill the chip
-  // feature passes: 256 wide, or 192 wide when that divides N better (384 = 2 x 192)
-  const int bn = (c.N % 256 == 0) ? 256 : (c.N % 192 == 0 ? 192 : 256);
-  const int npass = (c.N + bn - 1) / bn;
-  // output rows per tile: whole rows, at most 256 pixels (16 MFMA row tiles), at least 129 (9 row tiles; smaller
+  // feature passes: 256 wide; N = 384 k: 384 wide (wave = 96 x 96 outputs, 144 accumulator registers) when the band
+  // has at most 12 row tiles, else 192 wide (two passes).  One pass of 384 instead of two of 192 halves the A
+  // fragment reads per MFMA and the per-pass overhead (variant 54 keeps two passes, for comparison).
+  // Output rows per tile: whole rows, at most 256 pixels (16 MFMA row tiles), at least 129 (9 row tiles; smaller
   // images go to the tiled kernel, which packs several of them into a tile).  Among those, the band height that
   // needs the fewest (rounds over the CUs) x (row tiles per wave): 125 images of 27 x 27 are 375 bands of 9 rows
   // (2 rounds of 8 row tiles) or 500 bands of 7 (2 rounds of 6)
@@ -397,26 +397,41 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   }
   int grid = props[dev].multiProcessorCount / 8 * 8;
   if (grid < 8) grid = 8;
-  int RT = 0;
-  {
+  auto pick_rows = [&](int npass_, bool narrow_only) {
+    int best_rt = 0;
     int rt_max = 256 / c.OW;
     if (rt_max > c.OH) rt_max = c.OH;
     double best = 0;
     for (int rt = rt_max; rt >= 1; --rt) {
       const int tm = (rt * c.OW + 15) / 16;
       if (tm < 9) break;
+      if (narrow_only && tm > 12) continue;
       const int bd = (c.OH + rt - 1) / rt;
       long units = (long)n_img * bd;
-      if (units < grid && npass > 1) units *= npass;
+      if (units < grid && npass_ > 1) units *= npass_;
       const long rounds = (units + grid - 1) / grid;
-      const double cost = (double)rounds * ((tm <= 12 ? 6 : 8) + 1.5) * ((units < grid && npass > 1) ? 1 : npass);
-      if (RT == 0 || cost < best * 0.97) {
-        RT = rt;
+      const double cost = (double)rounds * ((tm <= 12 ? 6 : 8) + 1.5) * ((units < grid && npass_ > 1) ? 1 : npass_);
+      if (best_rt == 0 || cost < best * 0.97) {
+        best_rt = rt;
         best = cost;
       }
     }
-  }
+    return best_rt;
+  };
+  int bn = (c.N % 256 == 0) ? 256 : (c.N % 192 == 0 ? 192 : 256);
+  int npass = (c.N + bn - 1) / bn;
+  int RT = pick_rows(npass, false);
   if (RT == 0) return 0;
+  if (c.N % 384 == 0 && ctx->variant != 54) {
+    const int rt6 = pick_rows(c.N / 384, true);
+    // (only when a whole-chip round of 384-wide bands exists: with few bands the two passes are units of their own)
+    if (rt6 != 0 && (long)n_img * ((c.OH + rt6 - 1) / rt6) >= grid && (rt6 * c.OW + 15) / 16 <= 12 &&
+        ((RT * c.OW + 15) / 16 <= 12)) {
+      bn = 384;
+      npass = c.N / 384;
+      RT = rt6;
+    }
+  }
   const int bands = (c.OH + RT - 1) / RT;
   const int PT = RT * c.OW;
   const int TM = (PT + 15) / 16;
@@ -474,7 +489,7 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     static std::mutex mu;
     static std::unordered_map<void*, int> key_of;
     std::lock_guard<std::mutex> lock(mu);
-    const int key = row_par | (bn << 1);
+    const int key = row_par | (bn << 1);  // (bn: the fragment order depends on the pass width)
     if (*c.wcache == nullptr || key_of[*c.wcache] != key) {
       void* buf = *c.wcache;
       if (buf == nullptr) I8IE_TRY(i8ie_malloc(ctx, perm_bytes + bf_bytes, &buf));
@@ -546,6 +561,7 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   if (TMW == 8 && bn == 256) rc = launch_pc<8, 4>(ctx, a, grid, lds);
   else if (TMW == 6 && bn == 256) rc = launch_pc<6, 4>(ctx, a, grid, lds);
   else if (TMW == 6 && bn == 192) rc = launch_pc<6, 3>(ctx, a, grid, lds);
+  else if (TMW == 6 && bn == 384) rc = launch_pc<6, 6>(ctx, a, grid, lds);
   else rc = launch_pc<8, 3>(ctx, a, grid, lds);
   if (rc == I8IE_OK && ctx->variant == 51 && std::getenv("I8IE_PCONV_STAMPS") != nullptr) {
     std::vector<unsigned long long> h((size_t)grid * 8);

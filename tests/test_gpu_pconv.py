@@ -1,4 +1,4 @@
-"""The patch-stationary convolution kernels (csrc/i8ie_pconv.hip: variant 50; csrc/i8ie_tconv.hip: variant 70)
+"""The patch-stationary convolution kernels (csrc/i8ie_pconv.hip: variants 50 and 54 (N = 384 as two passes of 192 instead of one of 384); csrc/i8ie_tconv.hip: variant 70)
 against the oracle, through the C-ABI.
 
 Every output byte of the whole batch is compared.  Geometries hit: one feature pass of 256, two passes of 192
@@ -18,7 +18,7 @@ import synth
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {50: "pconv", 70: "tconv"}
+VARIANTS = {50: "pconv", 54: "pconv", 70: "tconv"}
 
 
 @pytest.fixture(scope="module")
