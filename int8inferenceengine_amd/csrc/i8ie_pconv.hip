@@ -73,7 +73,7 @@ struct PCArgs {
   uint8_t* out;
   unsigned out_bytes;
   int ob, OHp, OWp;
-  int lds_patch, lds_ocp, lds_tab, lds_ktab;  // LDS offsets
+  int lds_patch, lds_ocp, lds_tab, lds_ktab, lds_src, lds_prog;  // LDS offsets (lds_src < 0: no room for the source table)
   int split;                // 1: a (band, feature pass) pair is a unit of its own (small batches: more units than CUs)
   int flags;                // 1 = weights of the next pass fetched by the last K tile (not with split)
   unsigned long long* dbg;  // variant 51: per block, cycles spent per phase (wave 0)
@@ -160,15 +160,23 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
 
   // ---- the patch of a tile -> LDS (pixel pitch P: C bytes + one pad chunk), then one xor pass (u8 -> s8)
   const int CC1 = p.CC + 1;
+  // source offset of granule g relative to the patch origin: the same for every band, so it is tabulated once
+  // (two float divisions per granule at every fill took 2.2-3.7 k cycles per band)
+  auto src_of = [&](int g) {
+    int row, rem, pix, ch;
+    pc_divmod(g, p.row_gran, p.rcpRowGran, row, rem);
+    pc_divmod(rem, CC1, p.rcpCC1, pix, ch);
+    if (pix >= p.Wp) pix = 0;  // (row padding: any readable bytes)
+    return (unsigned)row * p.row_pitch + (unsigned)pix * p.C + (unsigned)(ch < p.CC ? ch : 0) * 16u;
+  };
+  if (p.lds_src >= 0) {
+    for (int g = tid; g < p.patch_gran; g += 512) reinterpret_cast<unsigned*>(smem + p.lds_src)[g] = src_of(g);
+  }
   auto patch_fill = [&](int t, int dst) {
     const int img = t / p.bands, band = t - img * p.bands;
     const unsigned src0 = (unsigned)img * p.img_pitch + (unsigned)(band * p.RT * p.s) * p.row_pitch;
     for (int g0 = 0; g0 < p.patch_gran; g0 += 512) {
-      int row, rem, pix, ch;
-      pc_divmod(g0 + tid, p.row_gran, p.rcpRowGran, row, rem);
-      pc_divmod(rem, CC1, p.rcpCC1, pix, ch);
-      if (pix >= p.Wp) pix = 0;  // (row padding: any readable bytes)
-      const unsigned so = src0 + (unsigned)row * p.row_pitch + (unsigned)pix * p.C + (unsigned)(ch < p.CC ? ch : 0) * 16u;  // (bounds: the descriptor)
+      const unsigned so = src0 + (p.lds_src >= 0 ? reinterpret_cast<const unsigned*>(smem + p.lds_src)[g0 + tid] : src_of(g0 + tid));  // (bounds: the descriptor)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(smem + dst + (g0 + wave * 64) * 16), 16,
                                                (int)so, 0, 0, 0);
     }
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   };
 
   // =============================== tile loop ===========================================================
-  unsigned long long ph[4] = {0, 0, 0, 0}, tq = 0;
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
   auto stamp = [&](int i) {
     if (p.dbg) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -296,6 +304,10 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
       load_A(Alo[0], 0, patch, k0);
 #pragma clang loop unroll(disable)
       for (int kt = 0; kt < p.nkt; ++kt, ++lin) {
+        // (Measured and dropped: equalising the two waves of a SIMD -- priority turns per K tile, or the wave behind,
+        // by a K-tile count published in LDS, at the higher priority.  Without it the older wave finishes its K
+        // loop 8 k cycles early (37 k vs 45 k on conv2) and waits at the hand-over barrier; with it both take 46 k:
+        // the pair's combined rate is what is limited, 85-88 % of the MFMA rate, and conv5 lost 4 %.)
         const int ktn = kt + 1 < p.nkt ? kt + 1 : kt;
         const int linn = kt + 1 < p.nkt ? lin + 1 : (xpre ? (lin + 1 < lin_total ? lin + 1 : 0) : lin);  // (xpre: not with split)
         k1 = k_at(kt, 1);
@@ -319,20 +331,23 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
     }
     // ---- hand-over: everyone is done with the patch -> request the next one -> it lands under the epilogue
     __syncthreads();
+    stamp(2);  // waiting for the slowest wave's K loop
     if (more) patch_fill(tile_of(unit + per), patch);
-    stamp(2);
+    stamp(3);  // issuing the patch DMA
     epilogue(tile, pass_hi - 1);
     stamp(1);
     if (more) {
       pc_wait_vm<ST>();  // all but the epilogue's stores
+      stamp(4);          // patch DMA not yet landed after the epilogue
       patch_xor(patch);
+      stamp(5);          // re-bias pass
     }
     __syncthreads();
-    stamp(2);
+    stamp(6);  // second barrier
   }
   pc_wait_vm<0>();
-  if (p.dbg && tid == 0)
-    for (int i = 0; i < 3; ++i) p.dbg[blockIdx.x * 8 + i] = ph[i];
+  if (p.dbg && lane == 0)
+    for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
 }
 
 // ---- weights in fragment order for this kernel's K walk: [pass][kt][ks][ntile][lane][16] --------------------
@@ -478,8 +493,9 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   if (out_bytes >= ((size_t)1 << 31) || c.a_bytes >= ((size_t)1 << 32) - 4096) return 0;
   // LDS plan: [patch] [oc'] [tables]
   const int kt_bytes = bn * 128;
-  const int fixed = npass * bn * 4 + 2 * kTabPix * 4 + nkt * 32;
+  const int fixed = npass * bn * 4 + 2 * kTabPix * 4 + nkt * 32 + 64;
   if (patch_gran * 16 + fixed > 160 * 1024) return 0;
+  const bool src_tab = patch_gran * 16 + fixed + patch_gran * 4 <= 160 * 1024;
 
   // ---- fragment-packed weights (once per layer: the slot lives in the layer handle)
   // (the slot holds [perm: nkt * 8 ints, padded to 256 B][weights]; re-packed when the pairing key changes)
@@ -542,7 +558,9 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.lds_ocp = patch_gran * 16;
   a.lds_tab = a.lds_ocp + npass * bn * 4;
   a.lds_ktab = a.lds_tab + 2 * kTabPix * 4;
-  const int lds = a.lds_ktab + nkt * 32;
+  a.lds_prog = a.lds_ktab + nkt * 32;
+  a.lds_src = src_tab ? a.lds_prog + 64 : -1;
+  const int lds = a.lds_prog + 64 + (src_tab ? patch_gran * 4 : 0);
 
   const double ops = 2.0 * c.M * c.N * c.Ktrue;
   const double bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
@@ -553,8 +571,8 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   I8ieProfScope prof(ctx, ctx->prof ? tag : nm, ops, bytes);
   static unsigned long long* dbg_dev = nullptr;
   if (ctx->variant == 51) {
-    if (!dbg_dev) I8IE_HIP_TRY(hipMalloc(&dbg_dev, 4096 * 8 * sizeof(unsigned long long)));
-    I8IE_HIP_TRY(hipMemsetAsync(dbg_dev, 0, 4096 * 8 * sizeof(unsigned long long), ctx->stream));
+    if (!dbg_dev) I8IE_HIP_TRY(hipMalloc(&dbg_dev, 4096 * 64 * sizeof(unsigned long long)));
+    I8IE_HIP_TRY(hipMemsetAsync(dbg_dev, 0, 4096 * 64 * sizeof(unsigned long long), ctx->stream));
     a.dbg = dbg_dev;
   }
   int rc;
@@ -564,15 +582,19 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   else if (TMW == 6 && bn == 384) rc = launch_pc<6, 6>(ctx, a, grid, lds);
   else rc = launch_pc<8, 3>(ctx, a, grid, lds);
   if (rc == I8IE_OK && ctx->variant == 51 && std::getenv("I8IE_PCONV_STAMPS") != nullptr) {
-    std::vector<unsigned long long> h((size_t)grid * 8);
+    std::vector<unsigned long long> h((size_t)grid * 64);
     I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
     I8IE_HIP_TRY(hipMemcpy(h.data(), dbg_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum[3] = {};
+    double sum[8][7] = {};
     for (int b = 0; b < grid; ++b)
-      for (int i = 0; i < 3; ++i) sum[i] += (double)h[(size_t)b * 8 + i];
+      for (int w = 0; w < 8; ++w)
+        for (int i = 0; i < 7; ++i) sum[w][i] += (double)h[((size_t)b * 8 + w) * 8 + i];
     const double tp = (double)a.n_tiles * npass;  // band passes in all
-    fprintf(stderr, "pconv_stamps v%d M %d N %d K %d (%d tiles x %d passes, %d K tiles, TMW %d bn %d): per tile pass, cycles: K loop %.0f (%.0f per K tile) | epilogue %.0f | hand-over (barriers, patch wait, re-bias) %.0f\n",
-            ctx->variant, c.M, c.N, c.Kchunks * 16, a.n_tiles, npass, nkt, TMW, bn, sum[0] / tp, sum[0] / tp / nkt, sum[1] / tp, sum[2] / tp);
+    fprintf(stderr, "pconv_stamps v%d M %d N %d K %d (%d tiles x %d passes, %d K tiles, TMW %d bn %d): per tile pass, cycles (wave 0): K loop %.0f (%.0f per K tile) | epilogue %.0f | hand-over: barrier after the K loop %.0f, DMA issue %.0f, DMA wait after the epilogue %.0f, re-bias %.0f, barrier %.0f ; K loop / first barrier per wave:",
+            ctx->variant, c.M, c.N, c.Kchunks * 16, a.n_tiles, npass, nkt, TMW, bn, sum[0][0] / tp, sum[0][0] / tp / nkt, sum[0][1] / tp, sum[0][2] / tp,
+            sum[0][3] / tp, sum[0][4] / tp, sum[0][5] / tp, sum[0][6] / tp);
+    for (int w = 0; w < 8; ++w) fprintf(stderr, " %.0f/%.0f", sum[w][0] / tp, sum[w][2] / tp);
+    fprintf(stderr, "\n");
   }
   return rc == I8IE_OK ? 1 : rc;
 }
