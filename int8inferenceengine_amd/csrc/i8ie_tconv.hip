@@ -332,6 +332,7 @@ __global__ __launch_bounds__(512, 2) void tconv_kernel(TCArgs p) {
       }
       stamp(1);  // wait for the slice + re-bias
       if (part) {
+        if (p.flags & 4) __builtin_amdgcn_s_setprio(0);  // experiment: the requantising wave yields to the other team's MFMAs
         epilogue(tile0 + j * per, pass);
         stamp(2);  // epilogue
       }
@@ -485,7 +486,9 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     // the first K half is the longer one: the wave that goes on to the epilogue leaves the MFMA pipe to the other
     // team's wave earlier (epilogue ~ 5 k cycles ~ 2-3 K tiles of the pair)
     kt_split = (nkt + 1) / 2 + 1;
+    if (const char* e = std::getenv("I8IE_TCONV_SPLIT")) kt_split = std::atoi(e);  // tuning aid
     if (kt_split > nkt - 1) kt_split = nkt - 1;
+    if (kt_split < 1) kt_split = 1;
   }
   const size_t out_pixels = (size_t)n_img * (c.OH + 2 * c.ob) * (c.OW + 2 * c.ob);
   const size_t out_bytes = out_pixels * (size_t)c.N;
@@ -550,6 +553,7 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   if (ctx->variant == 72) a.flags = 1;
   if (ctx->variant == 73) a.flags = 2;
   if (ctx->variant == 74) a.flags = 3;
+  if (ctx->variant == 75) a.flags = 4;
 
   const double ops = 2.0 * c.M * c.N * c.Ktrue;
   const double bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
