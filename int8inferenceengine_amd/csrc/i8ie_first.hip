@@ -85,7 +85,9 @@ __device__ __forceinline__ uint32_t quant_exact(float x, float scale, float zpf,
 
 // IDX = uint32_t while the image has fewer than 2^31 groups (three 64-bit divisions per group were a large part
 // of this kernel's 53 M VALU wave-instructions per launch), int64_t beyond
-template <typename IDX>
+// VEC: the 4 pixels of a group are read per channel as two 8-byte loads from an in-image, 8-byte-aligned base
+// (w and pad even), whole 512-byte runs per wave-instruction instead of four 4-byte loads with a 16-byte stride
+template <typename IDX, bool VEC>
 __global__ __launch_bounds__(256) void quantize_repack_kernel(const float* __restrict__ x, uint8_t* __restrict__ out,
                                                               int64_t total, int c, int h, int w, int Hp, int WG,
                                                               int pad, float scale, float zpf, float rscale,
@@ -102,17 +104,34 @@ __global__ __launch_bounds__(256) void quantize_repack_kernel(const float* __res
     const int yc = y < 0 ? 0 : (y >= h ? h - 1 : y);
     const float* plane = x + ((size_t)img * c * h + yc) * w;
     float v[12];
-    int xc[4];
+    if constexpr (VEC) {
+      const int xb = x0 < 0 ? 0 : (x0 > w - 4 ? w - 4 : x0);
+      const int sft = x0 - xb;  // in-image pixel px of this group is element px + sft of the 4 loaded ones
 #pragma unroll
-    for (int px = 0; px < 4; ++px) {
-      const int xx = x0 + px;
-      xc[px] = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
-    }
+      for (int ch = 0; ch < 3; ++ch) {
+        const float* row = plane + (ch < c ? ch : 0) * cs + xb;
+        const float2 a = *reinterpret_cast<const float2*>(row), b = *reinterpret_cast<const float2*>(row + 2);
+        const float L[4] = {a.x, a.y, b.x, b.y};
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {  // unconditional (clamped) loads: all 12 in flight together
-      const float* row = plane + (ch < c ? ch : 0) * cs;
+        for (int px = 0; px < 4; ++px) {
+          int i = px + sft;
+          i = i < 0 ? 0 : (i > 3 ? 3 : i);
+          v[ch * 4 + px] = i == 0 ? L[0] : (i == 1 ? L[1] : (i == 2 ? L[2] : L[3]));
+        }
+      }
+    } else {
+      int xc[4];
 #pragma unroll
-      for (int px = 0; px < 4; ++px) v[ch * 4 + px] = row[xc[px]];
+      for (int px = 0; px < 4; ++px) {
+        const int xx = x0 + px;
+        xc[px] = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+      }
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {  // unconditional (clamped) loads: all 12 in flight together
+        const float* row = plane + (ch < c ? ch : 0) * cs;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) v[ch * 4 + px] = row[xc[px]];
+      }
     }
     uint32_t wds[4];
 #pragma unroll
@@ -432,14 +451,21 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
     I8ieProfScope prof(ctx, "quantize_repack_f32", 0.0, 4.0 * c.n * c.c * c.h * c.w + 16.0 * total);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    if (total < ((int64_t)1 << 31) - 256 * 4096)
-      quantize_repack_kernel<uint32_t><<<(int)blocks, 256, 0, ctx->stream>>>(
-          c.x, c.scratch, total, c.c, c.h, c.w, a.Hp, a.WG, c.pad, c.q_scale, (float)c.q_zp, 1.0f / c.q_scale,
-          (uint32_t)(c.q_zp & 0xFF));
-    else
-      quantize_repack_kernel<int64_t><<<(int)blocks, 256, 0, ctx->stream>>>(
-          c.x, c.scratch, total, c.c, c.h, c.w, a.Hp, a.WG, c.pad, c.q_scale, (float)c.q_zp, 1.0f / c.q_scale,
-          (uint32_t)(c.q_zp & 0xFF));
+    const bool vec = (c.w & 1) == 0 && (c.pad & 1) == 0 && c.w >= 4 && (reinterpret_cast<uintptr_t>(c.x) & 7u) == 0 &&
+                     ctx->variant != 61;  // (variant 61: the scalar-load form, for comparison)
+    const float rs = 1.0f / c.q_scale;
+    const uint32_t zp8 = (uint32_t)(c.q_zp & 0xFF);
+    if (total < ((int64_t)1 << 31) - 256 * 4096) {
+      if (vec)
+        quantize_repack_kernel<uint32_t, true><<<(int)blocks, 256, 0, ctx->stream>>>(c.x, c.scratch, total, c.c, c.h, c.w, a.Hp, a.WG, c.pad,
+                                                                                  c.q_scale, (float)c.q_zp, rs, zp8);
+      else
+        quantize_repack_kernel<uint32_t, false><<<(int)blocks, 256, 0, ctx->stream>>>(c.x, c.scratch, total, c.c, c.h, c.w, a.Hp, a.WG, c.pad,
+                                                                                   c.q_scale, (float)c.q_zp, rs, zp8);
+    } else {
+      quantize_repack_kernel<int64_t, false><<<(int)blocks, 256, 0, ctx->stream>>>(c.x, c.scratch, total, c.c, c.h, c.w, a.Hp, a.WG, c.pad,
+                                                                                c.q_scale, (float)c.q_zp, rs, zp8);
+    }
     I8IE_LAUNCH_CHECK();
     grouped = c.scratch;
   }

@@ -60,7 +60,7 @@ GEOMS = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 60])  # 60: quantize inside the convolution kernel's patch fill (opt-in)
+@pytest.mark.parametrize("variant", [0, 60, 61])  # 60: quantize inside the convolution kernel's patch fill (opt-in); 61: scalar loads in the quantize + repack pass
 @pytest.mark.parametrize("geom", GEOMS)
 def test_fused_first_layer_bit_exact(gpu, orc, geom, variant):
     n, c, h, w, kc, k, stride, pad = geom
