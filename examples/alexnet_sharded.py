@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1000, help="global batch")
     ap.add_argument("--batches", type=int, default=10)
+    ap.add_argument("--graph", action="store_true", help="replay this rank's forward as one HIP graph (small shards)")
+    ap.add_argument("--check", action="store_true", help="rank 0: compare the gathered logits with an unsharded forward")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -47,6 +49,11 @@ def main():
     runner = sharding.ShardedRunner(net, args.batch, 10)
     x_all = wl.synthetic_input("alexnet", args.batch, seed=1234)
     x_dev = i8ie.tensor(np.ascontiguousarray(runner.shard(x_all))).prefetch()
+    if args.graph:
+        from int8inferenceengine_amd.graph import GraphedForward
+
+        graphed = GraphedForward(net, x_dev)
+        runner.forward = lambda x: graphed()
 
     runner.run(x_dev)  # warm-up
     torch.cuda.synchronize()
@@ -65,6 +72,10 @@ def main():
     if rank == 0:
         print("%d GPU(s): %.0f images/s, logits %s, classes hit %d" % (world, args.batch * args.batches / dt, logits.shape,
                                                                       len(np.unique(logits.argmax(1)))))
+    if args.check and rank == 0:
+        want = net(i8ie.tensor(x_all)).numpy()  # the whole batch on one GPU, eagerly
+        assert np.array_equal(logits.view(np.uint32), want.view(np.uint32)), "sharded logits differ from the unsharded forward"
+        print("check ok: gathered logits identical to the unsharded forward")
     dist.destroy_process_group()
 
 
