@@ -447,6 +447,13 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
       RT = rt6;
     }
   }
+  // Few bands and a single 256-wide pass (conv5 of a 125-image shard: 125 bands on 256 CUs): two passes of 128 instead,
+  // each (band, pass) a unit of its own, so that every CU has work (variant 54 keeps the wide pass)
+  if (npass == 1 && bn == 256 && c.N % 128 == 0 && ctx->variant != 54 && (RT * c.OW + 15) / 16 <= 12 &&
+      (long)n_img * ((c.OH + RT - 1) / RT) * 4 < (long)grid * 3) {
+    bn = 128;
+    npass = c.N / 128;
+  }
   const int bands = (c.OH + RT - 1) / RT;
   const int PT = RT * c.OW;
   const int TM = (PT + 15) / 16;
@@ -580,6 +587,7 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   else if (TMW == 6 && bn == 256) rc = launch_pc<6, 4>(ctx, a, grid, lds);
   else if (TMW == 6 && bn == 192) rc = launch_pc<6, 3>(ctx, a, grid, lds);
   else if (TMW == 6 && bn == 384) rc = launch_pc<6, 6>(ctx, a, grid, lds);
+  else if (TMW == 6 && bn == 128) rc = launch_pc<6, 2>(ctx, a, grid, lds);
   else rc = launch_pc<8, 3>(ctx, a, grid, lds);
   if (rc == I8IE_OK && ctx->variant == 51 && std::getenv("I8IE_PCONV_STAMPS") != nullptr) {
     std::vector<unsigned long long> h((size_t)grid * 64);

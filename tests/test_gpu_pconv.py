@@ -60,6 +60,7 @@ GEOMS = [
                                         # pconv makes every (band, pass) a unit of its own
     (257, 256, 13, 13, 384, 3, 1, 1),   # AlexNet conv3 geometry; 257 tiles: one block runs two
     (66, 512, 13, 13, 192, 1, 1, 0),    # 1 x 1 kernel, K = 512 = 4 K tiles (the shortest K the team kernel takes)
+    (125, 384, 13, 13, 256, 3, 1, 1),   # conv5 of a 125-image shard: pconv splits N = 256 into two passes of 128, 250 units
 ]
 
 
