@@ -42,3 +42,8 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 // i8ie_tconv.hip: the patch-stationary contraction with two wave teams half a tile apart (epilogues, patch waits
 // and re-bias passes of one team under the MFMAs of the other).  Same return convention.
 int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
+
+// i8ie_flin.hip: Linear for few rows (m <= 256) in one launch: 16 features x 128 rows x all of K per block, both
+// operands through LDS stages.  Takes the amode-0 fields of the call (ksplit / partial unused).
+bool i8ie_flin_wants(int m, int n, int Kpad);
+int i8ie_flin_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);

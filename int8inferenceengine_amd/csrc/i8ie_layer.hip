@@ -554,11 +554,13 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
       return I8IE_OK;
     }
     I8ieIgemmCall c{};
+    // few rows: the one-launch kernel of i8ie_flin.hip (variant 11 keeps the tiled split-K kernel, for comparison)
+    const bool flin = !need_pad && ctx->variant != 11 && L->K % 16 == 0 && i8ie_flin_wants(m, L->n, L->Kpad);
     // split K when the output has too few tiles to fill the chip (small batch, or few features)
     const long tiles_m = (m + 127) / 128, blocks_est = tiles_m * ((L->n + 63) / 64);
     const int nk = L->Kpad / 128;
     int ksplit = 1;
-    if (blocks_est < 256 && nk >= 4) {
+    if (blocks_est < 256 && nk >= 4 && !flin) {
       ksplit = (int)((512 + blocks_est - 1) / blocks_est);
       if (ksplit > 8) ksplit = 8;
       if (ksplit > nk / 2) ksplit = nk / 2;
@@ -583,6 +585,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
     c.B = panel; c.Kpad = L->Kpad; c.Npad = L->Npad; c.N = L->n; c.ocp = L->ocp; c.biasf = L->biasf;
     c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
     c.out = out; c.ob = 0; c.acc = acc; c.Ktrue = L->K;
+    if (flin) return i8ie_flin_launch(ctx, c);
     return i8ie_igemm_launch(ctx, c);
   }
 
