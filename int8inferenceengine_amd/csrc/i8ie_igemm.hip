@@ -839,6 +839,60 @@ __global__ __launch_bounds__(256) void linear_smalln_kernel(SmallNArgs p) {
   }
 }
 
+// The same head for long K on the MFMA path: one block per 16 rows, the K steps of 64 bytes dealt round-robin to the
+// block's 8 waves, every wave's loads (one activation and one weight fragment per step, 16 bytes per lane) issued
+// before its first v_mfma_i32_16x16x64_i8, the 8 partial tiles joined through LDS.  The dot4 form above walks a chain
+// of 60 cross-lane adds per row after its loads (11-13 us for fc8 whatever the batch); this one is one memory
+// round trip, 8 MFMAs and one LDS exchange.
+constexpr int kHeadSteps = 8;  // K steps in flight per wave and round
+__global__ __launch_bounds__(512) void linear_head_mfma_kernel(SmallNArgs p) {
+  __shared__ __attribute__((aligned(16))) int part[8 * 16 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane >> 4, lr = lane & 15;
+  const int row0 = blockIdx.x * 16;
+  const size_t a_off = (size_t)row0 * p.lda;
+  const size_t a_left = (size_t)p.M * p.lda - a_off;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.A + a_off), 0,
+                                                                       (unsigned)(a_left < 0xFFFFF000u ? a_left : 0xFFFFF000u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.B), 0, (unsigned)(16 * p.Kpad), 0x00020000);
+  const unsigned av = (unsigned)lr * (unsigned)p.lda + (unsigned)lq * 16u;    // row r, bytes 16 q .. of a 64-byte step
+  const unsigned bv = (unsigned)lr * (unsigned)p.Kpad + (unsigned)lq * 16u;   // feature r
+  const int nks = p.Kpad / 64;
+  v4i acc = {0, 0, 0, 0};
+  for (int s0 = wave; s0 < nks; s0 += 8 * kHeadSteps) {
+    v4i a[kHeadSteps], b[kHeadSteps];
+#pragma unroll
+    for (int i = 0; i < kHeadSteps; ++i) {
+      const int ks = s0 + 8 * i;
+      const unsigned k = (unsigned)(ks < nks ? ks : 0) * 64u;
+      a[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(av + k), 0, 0));
+      b[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(bv + k), 0, 0));
+      if (ks >= nks) b[i] = v4i{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < kHeadSteps; ++i) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(b[i], a[i] ^ (int)0x80808080, acc, 0, 0, 0);
+  }
+  // lane (q, r) holds features 4q .. 4q + 3 of row r
+  *reinterpret_cast<v4i*>(&part[(wave * 16 + lr) * 16 + 4 * lq]) = acc;
+  __syncthreads();
+  if (tid < 256) {
+    const int r = tid >> 4, j = tid & 15;
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) c += part[(w * 16 + r) * 16 + j];
+    const int row = row0 + r;
+    if (row < p.M && j < p.N) {
+      c += p.ocp[j];
+      const size_t o = (size_t)row * p.N + j;
+      if (p.acc) p.acc[o] = c;
+      c = (int)((float)c + p.biasf[j]);  // src/fully_connected.cc:44
+      const int q = requant_exact((float)c, p.rq, p.relu_lo);
+      if (p.out) p.out[o] = (uint8_t)q;
+      if (p.out_f32) p.out_f32[o] = (float)(q - p.dq_zp) * p.dq_scale;  // src/quantize_utils.cc:38-42
+    }
+  }
+}
+
 // Linear weight panel [rows][Kpad] with K reordered from the reference's flattened NCHW (c, h*w) to the
 // flattened NHWC (h*w, c) of the engine's activations; padding columns stay zero
 __global__ __launch_bounds__(256) void permute_k_kernel(const int8_t* __restrict__ B, int8_t* __restrict__ Bp,
@@ -1208,7 +1262,11 @@ int i8ie_launch_linear_smalln(i8ie_ctx* ctx, const I8ieSmallNCall& c) {
   a.relu_lo = c.relu ? c.zp_out : 0;
   a.out = c.out; a.acc = c.acc; a.out_f32 = c.out_f32; a.dq_scale = c.s_out; a.dq_zp = c.zp_out;
   I8ieProfScope prof(ctx, "linear_smalln_dot4", 2.0 * c.M * c.N * c.K, (double)c.M * c.K + (double)c.N * c.K + 5.0 * c.M * c.N);
-  if (c.K >= 2048)
+  // (activation rows are lda = K bytes apart and the weights are zero from K to Kpad: a step past K multiplies
+  // the next row's bytes, or the zeros the descriptor returns past the buffer, by zero)
+  if (c.K >= 1024 && c.Kpad % 64 == 0 && (size_t)16 * c.lda + c.Kpad < ((size_t)1 << 31) && ctx->variant != 11)
+    linear_head_mfma_kernel<<<(c.M + 15) / 16, 512, 0, ctx->stream>>>(a);
+  else if (c.K >= 2048)
     linear_smalln_kernel<4><<<c.M, 256, 0, ctx->stream>>>(a);
   else
     linear_smalln_kernel<1><<<(c.M + 3) / 4, 256, 0, ctx->stream>>>(a);
