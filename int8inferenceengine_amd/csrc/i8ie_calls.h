@@ -45,5 +45,5 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 
 // i8ie_flin.hip: Linear for few rows (m <= 256) in one launch: 16 features x 128 rows x all of K per block, both
 // operands through LDS stages.  Takes the amode-0 fields of the call (ksplit / partial unused).
-bool i8ie_flin_wants(int m, int n, int Kpad);
+bool i8ie_flin_wants(int m, int n, int Kpad, bool force);
 int i8ie_flin_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);

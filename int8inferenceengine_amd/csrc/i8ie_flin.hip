@@ -136,8 +136,12 @@ __global__ __launch_bounds__(512) void flin_kernel(FlinArgs p) {
 }  // namespace
 
 // one row group only: at 129-256 rows every CU would read the activations twice over and the tiled split-K kernel wins
-// (fc6 at 250 rows: 38 us here, 30 us tiled; at 125 rows: 21 vs 23 + its reduction launch)
-bool i8ie_flin_wants(int m, int n, int Kpad) { return m <= kRows && n >= 256 && Kpad >= 1024 && Kpad % kChunk == 0; }
+// (fc6 at 250 rows: 38 us here, 30 us tiled; at 125 rows: 21 vs 23 + its reduction launch); and enough features to
+// give half the CUs a block (a block's time does not depend on N: it streams all of the activations).  `force`
+// (kernel variant 80) lifts the feature threshold, for tests.
+bool i8ie_flin_wants(int m, int n, int Kpad, bool force) {
+  return m <= kRows && n >= (force ? 16 : 2048) && Kpad >= 1024 && Kpad % kChunk == 0;
+}
 
 int i8ie_flin_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   I8IE_REQUIRE(c.amode == 0 && c.M > 0 && c.N > 0 && c.Kpad % kChunk == 0, "flin: shape");

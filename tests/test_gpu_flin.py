@@ -57,7 +57,7 @@ def test_flin_bit_exact(gpu, orc, mkn, relu):
         finally:
             abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
 
-    (out, acc, _), names = _kernels_run(gpu, lambda: run(0))
+    (out, acc, _), names = _kernels_run(gpu, lambda: run(0 if n >= 2048 else 80))  # (80: below the automatic feature threshold)
     assert "flin_128x16" in names, names
     want = orc.relu(c["out"], c["zp_out"]) if relu else c["out"]
     assert np.array_equal(acc, c["acc"]) and np.array_equal(out, want)
@@ -76,8 +76,15 @@ def test_flin_extreme_values(gpu, orc):
     qw[2::3] = rng.integers(-128, 128, (len(range(2, n, 3)), 9216))
     qb = rng.integers(-128, 128, n).astype(np.int8)
     for zp_in in (0, 255):
-        (out, acc, _), names = _kernels_run(gpu, lambda: gpu.layer_forward_fused("linear", q_in, qw, qb, 0.02, zp_in, 0.001,
-                                                                                 0.7, 128, relu=False))
+        def run():
+            lib = abi.lib()
+            abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 80))
+            try:
+                return gpu.layer_forward_fused("linear", q_in, qw, qb, 0.02, zp_in, 0.001, 0.7, 128, relu=False)
+            finally:
+                abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
+
+        (out, acc, _), names = _kernels_run(gpu, run)
         assert "flin_128x16" in names, names
         want, pre, _ = orc.linear(q_in, qw, qb, 0.02, zp_in, 0.001, 0.7, 128, want_acc=True)
         assert np.array_equal(acc, pre) and np.array_equal(out, want)
