@@ -115,6 +115,9 @@ class ShardedRunner:
         self._stage = [torch.empty((self.rows, self.n_classes), dtype=torch.float32, device="cuda") for _ in range(2)]
         self._side = torch.cuda.Stream()
         self._gathered = [None, None]
+        # equal shards: the gather's receive buffers are allocated once (no allocator traffic per batch)
+        self._even = self.n_total % self.world == 0
+        self._recv = [torch.empty((self.n_total, self.n_classes), dtype=torch.float32, device="cuda") for _ in range(2)] if self._even else None
         self._host = None
         if self.rank == 0:
             self._host = [torch.empty((self.n_total, self.n_classes), dtype=torch.float32).pin_memory() for _ in range(2)]
@@ -142,7 +145,13 @@ class ShardedRunner:
         ready.record(main)
         with torch.cuda.stream(self._side):     # off the compute stream: the next batch does not wait for the collective
             self._side.wait_event(ready)
-            full = gather_rows(self._stage[k], self.n_total, self.group)  # RCCL all-gather of the per-shard logits
+            if self._even:  # RCCL all-gather of the per-shard logits, straight into the preallocated buffer
+                import torch.distributed as dist
+
+                full = self._recv[k]
+                dist.all_gather_into_tensor(full, self._stage[k], group=self.group)
+            else:
+                full = gather_rows(self._stage[k], self.n_total, self.group)
             if self.rank == 0:
                 self._host[k].copy_(full, non_blocking=True)
             ev = torch.cuda.Event()
