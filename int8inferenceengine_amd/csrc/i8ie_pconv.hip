@@ -22,8 +22,12 @@
 //     ahead (weights of a layer are 0.6-1.3 MB: L2-resident; the two waves that need the same fragment ask for it
 //     at about the same time).  No barrier inside the K loop: 8 waves (2 along the pixels x 4 along the features,
 //     128 x 64 outputs each) run free between the tile's two hand-over points.
-//   * N = 384 runs as two feature passes of 192 over the same resident patch; tiles are whole bands, so 1000
-//     images of 13 x 13 give 1000 equal tiles.
+//   * N = 384 runs as one pass of 384 over the resident patch (wave = 96 x 96 outputs) when a band has at most 12
+//     row tiles, else as two passes of 192; tiles are whole bands, so 1000 images of 13 x 13 give 1000 equal
+//     tiles.  With fewer bands than CUs the passes of a band (two of 192, or two of 128 cut from a 256-wide one)
+//     become units of their own; the band height is the one that needs the fewest rounds x row tiles.
+//   * K chunks are paired by the parity of their LDS slot (host-built permutation, shared with the weight
+//     packing), patch rows are padded to keep the 16-slot walk across row wraps: 6 % conflict cycles left.
 //   * The next band's patch is requested when the last K step of a tile has been read (one barrier) and lands
 //     under the epilogue; a counted vmcnt leaves the epilogue's stores in flight.  (Two alternating patch buffers,
 //     where they fit, were measured and bought nothing: vmcnt retires in order, so any wait on a weight fragment
