@@ -58,6 +58,16 @@ int i8ie_sync(i8ie_ctx* ctx);
 /* I8IE_OPT_KERNEL_VARIANT = 2 selects among compiled variants of the contraction kernel (all
  * produce identical bytes; a tuning / A-B timing aid, 0 = default). */
 #define I8IE_OPT_KERNEL_VARIANT 2
+/* The values the product library understands (anything else behaves like 0; the diagnostic build of tools/diag
+ * adds timing experiments under further numbers, listed in tools/README.md): */
+#define I8IE_VARIANT_AUTO 0            /* automatic selection per launch */
+#define I8IE_VARIANT_IGEMM_REGSTAGE 3  /* tiled contraction kernel, one LDS stage filled through registers (Linear's default) */
+#define I8IE_VARIANT_IGEMM_DMA 5       /* tiled contraction kernel, one LDS stage filled by LDS-DMA (the tiled conv default) */
+#define I8IE_VARIANT_TILED 11          /* tiled contraction kernel everywhere: no patch-stationary conv, split-K Linear, dot4 head */
+#define I8IE_VARIANT_PCONV 50          /* patch-stationary conv kernel (csrc/i8ie_pconv.hip) at any batch size */
+#define I8IE_VARIANT_PCONV_2PASS 54    /* the same, N = 384 as two passes of 192 and no 128-wide pass split */
+#define I8IE_VARIANT_TCONV 70          /* two-team patch-stationary conv kernel (csrc/i8ie_tconv.hip) wherever its shape rules allow */
+#define I8IE_VARIANT_FLIN 80           /* few-row Linear kernel (csrc/i8ie_flin.hip) below its automatic feature threshold */
 /* I8IE_OPT_PROFILE_STRIDE = 3: while profiling, bracket only every value-th eligible launch
  * (default 1 = all).  Event packets cost a few microseconds each on the stream; a stride that is
  * coprime with the launches per batch samples every kernel over a few batches. */
@@ -110,6 +120,13 @@ int i8ie_memset(i8ie_ctx* ctx, void* dst_dev, int byte, size_t bytes);
  * that would synchronise inside it fails the capture with I8IE_ERR_HIP).  Replays are ordered on the ctx's
  * stream like any other launch; inputs and outputs are the device buffers the captured calls used. */
 typedef struct i8ie_graph i8ie_graph;
+/* While graphs captured on a ctx are alive its workspace is pinned: a later call that needs a larger one gets a new
+ * allocation and the old one stays until the last graph is destroyed.  Weights re-packed by a kernel are kept per
+ * packing key in the layer handle and never overwritten, so a replay after an eager forward at another batch size
+ * still finds its own.  A layer handle must outlive the graphs that captured its forward.
+ * i8ie_ctx_is_capturing: *yes = 1 between begin and end (owners of cached device blocks use it to route frees
+ * to i8ie_free, which hands the block to the graph, instead of to a cache of their own). */
+int i8ie_ctx_is_capturing(i8ie_ctx* ctx, int* yes);
 int i8ie_graph_begin(i8ie_ctx* ctx);
 int i8ie_graph_end(i8ie_ctx* ctx, i8ie_graph** out);
 int i8ie_graph_launch(i8ie_graph* g);
@@ -171,18 +188,6 @@ int i8ie_calib_sample_f32(i8ie_ctx* ctx, const float* data_dev, int64_t n, int64
 /* down_scale  src/quantize_utils.cc:27-36 (standalone requantiser; the layers fuse it) */
 int i8ie_down_scale(i8ie_ctx* ctx, const int32_t* acc_dev, uint8_t* out_dev, int64_t n, float sa,
                     float sb, float sc, uint8_t zp_c);
-
-/* ---- host side of the requantiser (no device, no ctx) ---------------------------
- * The large-convolution kernel requantises with a two-operation estimate
- * fma((float)C, ms, bias) -> round-to-nearest-even -> saturate, used only after
- * i8ie_requant_fit_host() has PROVEN it equal to down_scale (+ relu) of
- * src/quantize_utils.cc:27-36 for every int32 accumulator (csrc/i8ie_requant.h).
- * fit: returns 1 and the constants when such (ms, bias) exist, 0 otherwise (the
- * kernel then keeps the guarded / exact sequence).  eval: both functions on a host
- * array of accumulators, for tests. */
-int i8ie_requant_fit_host(float sa, float sb, float sc, int zp_c, int relu, float* ms, float* bias);
-int i8ie_requant_eval_host(float sa, float sb, float sc, int zp_c, int relu, float ms, float bias,
-                           const int32_t* acc_host, int64_t n, uint8_t* exact_host, uint8_t* estimate_host);
 
 /* ---- FP32 ops: the path taken before convert() and while calibrating -------
  * Conv2d/Linear::forward_prop(Tensor<float>&&)  src/conv2d.cc:63-98, src/fully_connected.cc:5-21
@@ -282,10 +287,11 @@ int i8ie_layer_preferred_layout(const i8ie_layer* layer, int* layout);
  * src/conv2d.cc:100-142 on it, writes the interior of an NHWC u8 tensor (+ optional relu).  Only for layers and
  * geometries where i8ie_layer_accepts_f32_input says yes (<= 3 channels, stride % 4 == 0,
  * out features % 32 == 0): AlexNet's 11x11 stride-4 conv1.  Identical bytes to
- * i8ie_quantize_f32_u8 followed by i8ie_layer_forward_fused. */
+ * i8ie_quantize_f32_u8 followed by i8ie_layer_forward_fused.  acc_dbg_dev: NULL, or int32 [m, oh*ow, kc] receiving
+ * the pre-requant accumulators (the MKL result, src/conv2d.cc:131-133), as in the other forward calls. */
 int i8ie_layer_accepts_f32_input(const i8ie_layer* layer, int h, int w, int* yes);
 int i8ie_layer_forward_f32_input(i8ie_layer* layer, const float* in_nchw_dev, int m, int h, int w, float q_scale,
-                                 uint8_t q_zp, int relu, uint8_t* out_nhwc_dev, int out_border);
+                                 uint8_t q_zp, int relu, uint8_t* out_nhwc_dev, int out_border, int32_t* acc_dbg_dev);
 /* padding of a conv layer (0 for Linear): the input border that makes its gather predicate-free */
 int i8ie_layer_padding(const i8ie_layer* layer, int* pad);
 int i8ie_layer_destroy(i8ie_layer* layer);

@@ -3,7 +3,25 @@
 #include <cstddef>
 #include <cstdint>
 
+#include <vector>
+
 struct i8ie_ctx;
+
+// Weights re-packed by a contraction kernel for its own K walk, cached in the layer handle: one buffer per packing
+// key (the fragment order depends on the pass width, which depends on the batch size), never overwritten once made --
+// a captured HIP graph keeps replaying the address it was captured with -- and freed with the layer.
+struct I8ieWCache {
+  struct Ent {
+    unsigned long long key;
+    void* buf;
+  };
+  std::vector<Ent> ents;
+  void* find(unsigned long long key) const {
+    for (const Ent& e : ents)
+      if (e.key == key) return e.buf;
+    return nullptr;
+  }
+};
 
 // one contraction launch: Linear (amode 0) or implicit-GEMM Conv2d over bordered NHWC (amode 1)
 struct I8ieIgemmCall {
@@ -25,18 +43,18 @@ struct I8ieIgemmCall {
   double Ktrue;
   int ksplit;        // amode 0 only: > 1 = split K over that many slices (partial must hold ksplit*M*N int32)
   int32_t* partial;
-  void** wcache;     // amode 1: slot in the layer handle for weights re-packed by a kernel (i8ie_pconv.hip); may be null
-  void** wcache2;    // the same for i8ie_tconv.hip (its K order differs)
+  I8ieWCache* wcache;  // amode 1: the layer handle's cache of weights re-packed by i8ie_pconv.hip / i8ie_tconv.hip; may be null
 };
 int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 
-// i8ie_pp.hip: the persistent ping-pong form of the amode-1 contraction (large convolutions).
-// Returns 1 when it took the launch, 0 when the shape is not its (the caller then runs the tiled kernel),
-// < 0 on error.
+#if defined(I8IE_DIAG)
+// tools/diag/csrc/i8ie_pp.hip (diagnostic build only): the persistent ping-pong form of the amode-1 contraction.
 int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
+#endif
 
 // i8ie_pconv.hip: the patch-stationary form of the amode-1 contraction (input patch resident in LDS, weights
-// streamed in fragment order).  Same return convention as i8ie_pp_try_launch.
+// streamed in fragment order).  Returns 1 when it took the launch, 0 when the shape is not its (the caller then
+// runs the tiled kernel), < 0 on error.
 int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 
 // i8ie_tconv.hip: the patch-stationary contraction with two wave teams half a tile apart (epilogues, patch waits

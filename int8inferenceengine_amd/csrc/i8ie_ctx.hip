@@ -139,6 +139,11 @@ int i8ie_ctx_destroy(i8ie_ctx* ctx) {
   for (auto& kv : pool_of(ctx)->live) (void)hipFree(kv.first);  // leaked by the caller
   delete pool_of(ctx);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->retired_ws) {
+    auto* r = static_cast<std::vector<void*>*>(ctx->retired_ws);
+    for (void* w : *r) (void)hipFree(w);
+    delete r;
+  }
   if (ctx->copy_stream) {
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
@@ -467,6 +472,12 @@ struct i8ie_graph {
   std::vector<void*> held;  // blocks freed during the capture
 };
 
+int i8ie_ctx_is_capturing(i8ie_ctx* ctx, int* yes) {
+  I8IE_REQUIRE(ctx != nullptr && yes != nullptr, "null argument");
+  *yes = ctx->capture != nullptr ? 1 : 0;
+  return I8IE_OK;
+}
+
 int i8ie_graph_begin(i8ie_ctx* ctx) {
   I8IE_REQUIRE(ctx != nullptr, "null ctx");
   I8IE_REQUIRE(ctx->capture == nullptr, "a capture is already open on this ctx");
@@ -505,6 +516,7 @@ int i8ie_graph_end(i8ie_ctx* ctx, i8ie_graph** out) {
   }
   i8ie_graph* g = new i8ie_graph{ctx, graph, exec, std::move(*held)};
   delete held;
+  ctx->live_graphs += 1;  // (pins the workspace: i8ie_ws_reserve)
   *out = g;
   return I8IE_OK;
 }
@@ -539,6 +551,13 @@ int i8ie_graph_destroy(i8ie_graph* g) {
   (void)hipGraphExecDestroy(g->exec);
   (void)hipGraphDestroy(g->graph);
   for (void* b : g->held) (void)i8ie_free(g->ctx, b);
+  i8ie_ctx* ctx = g->ctx;
+  if (--ctx->live_graphs == 0 && ctx->retired_ws) {  // no replay can touch an outgrown workspace any more
+    auto* r = static_cast<std::vector<void*>*>(ctx->retired_ws);
+    for (void* w : *r) (void)hipFree(w);
+    delete r;
+    ctx->retired_ws = nullptr;
+  }
   delete g;
   return I8IE_OK;
 }
@@ -550,7 +569,14 @@ int i8ie_ws_reserve(i8ie_ctx* ctx, size_t bytes) {
   I8IE_REQUIRE(ctx->capture == nullptr, "workspace growth inside a graph capture: run the same calls once eagerly first");
   I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->ws) {
-    I8IE_HIP_TRY(hipFree(ctx->ws));
+    if (ctx->live_graphs > 0) {
+      // captured graphs replay kernels that read and write this workspace: it stays allocated until the last of
+      // them is destroyed; eager calls move on to the larger one
+      if (!ctx->retired_ws) ctx->retired_ws = new std::vector<void*>();
+      static_cast<std::vector<void*>*>(ctx->retired_ws)->push_back(ctx->ws);
+    } else {
+      I8IE_HIP_TRY(hipFree(ctx->ws));
+    }
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
   }

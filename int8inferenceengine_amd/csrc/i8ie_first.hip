@@ -67,6 +67,7 @@ struct FirstArgs {
   uint8_t* out;  // NHWC [n][OH + 2ob][OW + 2ob][N]
   int ob;
   int toff[2 * kMaxKS];  // LDS byte offset of K chunk q inside a pixel's window
+  int32_t* acc;          // ACC kernels: [n * OH * OW][N] pre-requant accumulators (the cblas_gemm_s8u8s32 result, src/conv2d.cc:131-133)
 };
 
 // ---- fused quantize + repack: FP32 NCHW -> grouped u8 [n][Hp][WG][16] -------------------------
@@ -194,7 +195,8 @@ __device__ __forceinline__ uint4 group_finish(const FirstArgs& p, const GroupLoa
   return make_uint4(wds[0], wds[1], wds[2], wds[3]);
 }
 
-template <int KS, bool FUSEQ>
+// ACC: also dump the INT32 accumulators (acc_dbg of the C-ABI) -- a separate instantiation, the default one is untouched
+template <int KS, bool FUSEQ, bool ACC>
 __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int nthreads = blockDim.x;
@@ -351,6 +353,15 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
           __builtin_amdgcn_sched_barrier(0);
         });
         // epilogue: lane = pixel, regs = features (4 consecutive per group)
+        if constexpr (ACC) {
+          const int am = it * 32 + (lane & 31);
+          if (am < npix) {
+            int32_t* arow = p.acc + ((size_t)img * (size_t)(p.OH * p.OW) + (size_t)(rb0 * p.OW + am)) * (size_t)p.N + wave * 32 + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<int4*>(arow + 8 * g) = make_int4(acc[g * 4 + 0], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]);
+          }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const uint32_t packed =
@@ -379,17 +390,24 @@ __global__ __launch_bounds__(512) void conv_smallc_kernel(FirstArgs p) {
   }
 }
 
-template <int KS, bool FUSEQ>
-int launch_first_q(i8ie_ctx* ctx, const FirstArgs& a, int blocks, int threads, size_t lds) {
-  I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_smallc_kernel<KS, FUSEQ>),
+template <int KS, bool FUSEQ, bool ACC>
+int launch_first_qa(i8ie_ctx* ctx, const FirstArgs& a, int blocks, int threads, size_t lds) {
+  I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_smallc_kernel<KS, FUSEQ, ACC>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  conv_smallc_kernel<KS, FUSEQ><<<blocks, threads, lds, ctx->stream>>>(a);
+  conv_smallc_kernel<KS, FUSEQ, ACC><<<blocks, threads, lds, ctx->stream>>>(a);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }
+template <int KS, bool FUSEQ>
+int launch_first_q(i8ie_ctx* ctx, const FirstArgs& a, int blocks, int threads, size_t lds) {
+  return a.acc != nullptr ? launch_first_qa<KS, FUSEQ, true>(ctx, a, blocks, threads, lds) : launch_first_qa<KS, FUSEQ, false>(ctx, a, blocks, threads, lds);
+}
 template <int KS>
 int launch_first(i8ie_ctx* ctx, const FirstArgs& a, int blocks, int threads, size_t lds) {
-  return a.x != nullptr ? launch_first_q<KS, true>(ctx, a, blocks, threads, lds) : launch_first_q<KS, false>(ctx, a, blocks, threads, lds);
+#if defined(I8IE_DIAG)  // quantize inside the patch fill: measured slower, diagnostic build only
+  if (a.x != nullptr) return launch_first_q<KS, true>(ctx, a, blocks, threads, lds);
+#endif
+  return launch_first_q<KS, false>(ctx, a, blocks, threads, lds);
 }
 
 }  // namespace
@@ -409,11 +427,14 @@ struct I8ieFirstCall {
   int zp_out, relu;
   uint8_t* out;
   int ob;
+  int32_t* acc;  // null, or [n * OH * OW][N]
 };
 
 int i8ie_first_supported(int c, int stride, int n_out, int K2, int KH, int KWG, int OW) {
+#if defined(I8IE_DIAG)
   static const bool off = std::getenv("I8IE_NO_SMALLC") != nullptr;  // A/B aid: route path B through the generic kernel
   if (off) return 0;
+#endif
   if (c > 3 || stride % 4 != 0) return 0;  // 3 data channels + 1 pad byte per pixel
   if (n_out % 32 != 0 || n_out / 32 > 8) return 0;
   if ((K2 + 31) / 32 > kMaxKS) return 0;
@@ -440,8 +461,12 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
   // form is bit-exact but 0.67 ms against 0.22 + 0.17 ms: ~100 VALU operations per 16-byte group land in waves
   // that are already VALU-bound (12 VALU per MFMA in the epilogue), the halo rows of every band are quantised
   // again (x 1.35), and 204 VGPRs leave two blocks per CU instead of three.  Kept as a tested opt-in.
+#if defined(I8IE_DIAG)
   static const bool fused_opt = std::getenv("I8IE_FIRST_FUSED") != nullptr;
   const bool fuse = c.x != nullptr && (fused_opt || ctx->variant == 60);  // (variant 60: per-ctx switch for tests / A-B runs)
+#else
+  const bool fuse = false;
+#endif
   if (fuse) {
     a.x = c.x; a.xc = c.c; a.xh = c.h; a.xw = c.w; a.xpad = c.pad;
     a.q_scale = c.q_scale; a.q_zpf = (float)c.q_zp; a.q_rscale = 1.0f / c.q_scale; a.q_zp = (uint32_t)(c.q_zp & 0xFF);
@@ -451,8 +476,10 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
     I8ieProfScope prof(ctx, "quantize_repack_f32", 0.0, 4.0 * c.n * c.c * c.h * c.w + 16.0 * total);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    const bool vec = (c.w & 1) == 0 && (c.pad & 1) == 0 && c.w >= 4 && (reinterpret_cast<uintptr_t>(c.x) & 7u) == 0 &&
-                     ctx->variant != 61;  // (variant 61: the scalar-load form, for comparison)
+    bool vec = (c.w & 1) == 0 && (c.pad & 1) == 0 && c.w >= 4 && (reinterpret_cast<uintptr_t>(c.x) & 7u) == 0;
+#if defined(I8IE_DIAG)
+    if (ctx->variant == 61) vec = false;  // (the scalar-load form, for comparison)
+#endif
     const float rs = 1.0f / c.q_scale;
     const uint32_t zp8 = (uint32_t)(c.q_zp & 0xFF);
     if (total < ((int64_t)1 << 31) - 256 * 4096) {
@@ -475,7 +502,9 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
   int RB = 1;
   size_t patch_budget = fuse ? 50 * 1024 : 44 * 1024;  // bytes for the two patches of a block (fused: taller bands
                                                         // re-quantise fewer halo rows; 50 KB still fits 3 blocks per CU)
+#if defined(I8IE_DIAG)
   if (const char* e = std::getenv("I8IE_FIRST_PATCH_KB")) patch_budget = (size_t)std::atoi(e) * 1024;
+#endif
   while (RB < c.OH && (size_t)(RB * a.sh + c.KH) * a.WG * 16 * 2 <= patch_budget && (RB + 1) * c.OW <= 512) ++RB;
   a.RB = RB;
   a.PR = (RB - 1) * a.sh + c.KH;
@@ -484,7 +513,7 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
   a.B = c.B; a.Kpad = c.Kpad; a.N = c.N; a.ocp = c.ocp;
   a.rq = i8ie_make_requant(c.s_in, c.s_w, c.s_out, c.zp_out);
   a.relu_lo = c.relu ? c.zp_out : 0;
-  a.out = c.out; a.ob = c.ob;
+  a.out = c.out; a.ob = c.ob; a.acc = c.acc;
   const int ks_needed = (c.K2 + 31) / 32;
   const int nchunks = c.KH * c.KWG;
   for (int q = 0; q < 2 * kMaxKS; ++q) {
@@ -495,7 +524,9 @@ int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c) {
   const size_t patch_lds = fuse ? (size_t)a.PR * a.WG * 16 : (((size_t)a.PR * a.WG * 16 + 1023) & ~(size_t)1023);
   const size_t lds = 2 * patch_lds + (size_t)waves * 32 * 36;
   int per_cu = 3;  // blocks launched per CU (measured on AlexNet conv1 with the DMA fill: 3 beats 2, 4 and 6)
+#if defined(I8IE_DIAG)
   if (const char* e = std::getenv("I8IE_FIRST_BLOCKS_PER_CU")) per_cu = std::atoi(e) > 0 ? std::atoi(e) : per_cu;
+#endif
   int blocks = 256 * per_cu;
   if (blocks > a.total_bands) blocks = a.total_bands;
   const double ops = 2.0 * c.n * c.OH * c.OW * (double)c.N * c.c * c.KH * c.KW;

@@ -1015,6 +1015,7 @@ int launch_tile_var(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, d
 template <int AMODE, bool BIAS, bool ACC>
 int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, double bytes) {
   if (AMODE == 1 && !BIAS && !ACC) {
+#if defined(I8IE_DIAG)  // tile-shape experiments, compiled into the diagnostic build only
     if (ctx->variant == 10) return launch_tile_var<1, false, false, 0>(ctx, a, kbytes, ops, bytes);
     if (ctx->variant == 6 && a.N <= 96 && a.N > 64)  // 256 x 96 tile, 4 waves of 64 x 96
       return launch_cfg<1, 4, 1, 2, 3, false, false, 3>(ctx, a, "igemm_conv_256x96", kbytes, ops, bytes);
@@ -1024,16 +1025,19 @@ int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, doubl
       return launch_cfg<1, 2, 2, 4, 2, false, false, 5>(ctx, a, "igemm_conv_256x128", kbytes, ops, bytes);
     if (ctx->variant == 9 && a.N > 128)  // 128 x 256, 4 waves of 64 x 128
       return launch_cfg<1, 2, 2, 2, 4, false, false, 5>(ctx, a, "igemm_conv_128x256", kbytes, ops, bytes);
+#endif
     // 192 x 128, 4 waves of 96 x 64, one DMA stage: 6.4 KB staged per MOP (128 x 128: 7.6) at three blocks
     // per CU; measured 2.5-4 % faster than 128 x 128 on AlexNet conv2-5 (variant 12 = 128 x 128 everywhere)
     if ((ctx->variant == 0 || ctx->variant == 11) && a.N > 64 && a.M >= 192 * 256)
       return launch_cfg<1, 2, 2, 3, 2, false, false, 5>(ctx, a, "igemm_conv_192x128", kbytes, ops, bytes);
+#if defined(I8IE_DIAG)
     if (ctx->variant == 7 && a.N > 128 && (long)((a.M + 255) / 256) >= 256) {
       // 4 waves of 128 x 128 or 128 x 96: whichever pads N less
       const int pad4 = (a.N + 255) / 256 * 256, pad3 = (a.N + 191) / 192 * 192;
       if (pad4 <= pad3) return launch_cfg<1, 2, 2, 4, 4, false, false, 7>(ctx, a, "igemm_conv_256x256", kbytes, ops, bytes);
       return launch_cfg<1, 2, 2, 4, 3, false, false, 7>(ctx, a, "igemm_conv_256x192", kbytes, ops, bytes);
     }
+#endif
   }
   // Linear (few, short split-K slices per block) measured 20 % slower with DMA staging: register staging there
   if (ctx->variant == 3 || (AMODE == 0 && ctx->variant != 5))
@@ -1095,6 +1099,7 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     }
     return I8IE_OK;
   }
+#if defined(I8IE_DIAG)
   // The persistent ping-pong kernel (i8ie_pp.hip) is opt-in (variant 20; 21-49 are its diagnostic builds): measured
   // on MI355X it trails the tiled kernel by 3-8 % on AlexNet conv2 / conv5 as long as activations need the u8 -> s8
   // xor in its MFMA slots ("what bounds the ping-pong kernel"), and it pads N = 384 to 512.
@@ -1102,6 +1107,7 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     const int took = i8ie_pp_try_launch(ctx, c);
     if (took != 0) return took < 0 ? took : I8IE_OK;
   }
+#endif
   // The two-team form of the patch-stationary kernel (i8ie_tconv.hip) comes first: it declines unless forced
   // (variant 70) or the launch is of the kind it measured faster on (one feature pass, >= 8 bands per CU).
   if (c.amode == 1 && (ctx->variant == 0 || (ctx->variant >= 70 && ctx->variant < 80))) {

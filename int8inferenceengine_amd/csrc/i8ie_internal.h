@@ -24,6 +24,8 @@ struct i8ie_ctx {
   hipStream_t copy_stream = nullptr;  // transfer stream for the *_async copies (created on first use)
   void* pinned = nullptr;  // std::unordered_map<void*, size_t>* of i8ie_host_malloc blocks
   void* capture = nullptr;  // std::vector<void*>* while a graph is being captured: blocks freed meanwhile (i8ie_graph_*)
+  int live_graphs = 0;      // graphs captured on this ctx and not yet destroyed: their kernels have ctx->ws baked in
+  void* retired_ws = nullptr;  // std::vector<void*>*: workspaces outgrown while graphs were alive (freed with the last graph)
 };
 
 // Per-launch HIP-event timing on the ctx's stream (off unless i8ie_profile_start was

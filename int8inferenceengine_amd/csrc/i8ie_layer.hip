@@ -47,10 +47,12 @@ struct I8ieSmallNCall {
   float* out_f32;
 };
 int i8ie_smalln_max_features();
+#if defined(I8IE_DIAG)  // tools/diag/csrc/i8ie_skinny.hip
 int i8ie_launch_frag_pack(i8ie_ctx* ctx, const int8_t* B, void* Bf, int Npad, int Kpad);
 int i8ie_skinny_plan(int m, int n, int Kpad, int* nstep, int* slices);
 int i8ie_launch_linear_skinny(i8ie_ctx* ctx, const uint8_t* A, size_t lda, int m, const void* Bf, int Kpad, int Npad,
                               int n, const int32_t* ocp, int32_t* partial, int nstep, int slices);
+#endif
 int i8ie_launch_splitk_reduce(i8ie_ctx* ctx, const int32_t* partial, int slices, int M, int N, const float* biasf,
                               float s_in, float s_w, float s_out, int zp_out, int relu, uint8_t* out, int32_t* acc);
 int i8ie_launch_linear_smalln(i8ie_ctx* ctx, const I8ieSmallNCall& c);
@@ -77,6 +79,7 @@ struct I8ieFirstCall {
   int zp_out, relu;
   uint8_t* out;
   int ob;
+  int32_t* acc;
 };
 int i8ie_first_supported(int c, int stride, int n_out, int K2, int KH, int KWG, int OW);
 int i8ie_first_launch(i8ie_ctx* ctx, const I8ieFirstCall& c);
@@ -191,8 +194,8 @@ struct i8ie_layer {
   int path = PATH_F;        // conv: PATH_A / PATH_B / PATH_F
   int8_t* Bpack2 = nullptr; // conv paths A/B: [Npad][Kpad2], K ordered (kh, kw, c) / grouped
   int K2 = 0, Kpad2 = 0;    // valid / padded K of Bpack2 (bytes)
-  void* Btconv = nullptr;   // the same for i8ie_tconv.hip
-  void* Bpconv = nullptr;   // Bpack2 in the fragment order of i8ie_pconv.hip (made on its first launch)
+  I8ieWCache wc;            // Bpack2 in the fragment orders of i8ie_pconv.hip / i8ie_tconv.hip: one buffer per packing
+                            // key, made on first use, never overwritten (captured graphs replay their addresses)
   int kwg = 0;              // path B: taps per row in 4-pixel groups
   int32_t* wsum = nullptr;  // [n]
   int32_t* oc = nullptr;    // [n], valid for (oc_s_in, oc_zp_in)
@@ -525,6 +528,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
       I8IE_TRY(layer_forward_impl(L, in, in_layout, 0, m, h, w, s_in, zp_in, relu, out, I8IE_LAYOUT_NCHW, 0, acc, nullptr));
       return i8ie_dequantize_u8_f32(ctx, out, out_f32, (int64_t)m * L->n, L->s_out, L->zp_out);
     }
+#if defined(I8IE_DIAG)
     int sk_steps = 0, sk_slices = 0;
     // opt-in ($I8IE_SKINNY=1): once the tiled split-K kernel wrote its partial tiles as row segments it became
     // the faster one even at m = 125 (fc6 + fc7: 33 us against 42 us), see DESIGN.md
@@ -546,6 +550,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
       return i8ie_launch_splitk_reduce(ctx, (const int32_t*)ctx->ws, sk_slices, m, L->n, L->biasf, s_in, L->s_w,
                                        L->s_out, L->zp_out, relu, out, acc);
     }
+#endif
     if (force_fallback(ctx)) {
       if (need_pad) I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->Kpad));
       I8IE_TRY(linear_run_v1(ctx, in, m, L->K, L->Bpack, L->Kpad, L->qb, L->n, L->oc, L->wsum, s_in, L->s_w, L->s_out,
@@ -622,7 +627,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
   I8ieIgemmCall c{};
   c.amode = 1; c.M = m * cg.oh * cg.ow;
   c.B = L->Bpack2; c.Kpad = L->Kpad2; c.Npad = L->Npad; c.Kchunks = L->K2 / 16; c.N = L->n; c.ocp = L->ocp;
-  c.biasf = nullptr; c.wcache = &L->Bpconv; c.wcache2 = &L->Btconv;
+  c.biasf = nullptr; c.wcache = &L->wc;
   c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
   c.acc = acc; c.Ktrue = cg.K; c.OH = cg.oh; c.OW = cg.ow;
   const size_t o_bytes = out_layout == I8IE_LAYOUT_NCHW ? i8ie_align_up(out_bytes, 256) : 0;
@@ -665,7 +670,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
       src = ws;
     }
     uint8_t* rep = ws + t_bytes;
-    const bool wstat = acc == nullptr && i8ie_first_supported(cg.c, cg.stride, L->n, L->K2, cg.kh, L->kwg, cg.ow);
+    const bool wstat = (acc == nullptr || (L->n % 4 == 0 && aligned16(acc))) && i8ie_first_supported(cg.c, cg.stride, L->n, L->K2, cg.kh, L->kwg, cg.ow);
     I8IE_TRY(i8ie_launch_repack_smallc(ctx, src, rep, m, cg.c, cg.h, cg.w, Hp, Wg, cg.pad, cg.pad, zp_in, wstat));
     if (wstat) {
       // weights-stationary small-C kernel (i8ie_first.hip) on the grouped image
@@ -677,7 +682,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
       f.KH = cg.kh; f.KW = cg.kw; f.KWG = L->kwg; f.stride = cg.stride; f.pad = cg.pad; f.OH = cg.oh; f.OW = cg.ow;
       f.B = L->Bpack2; f.Kpad = L->Kpad2; f.K2 = L->K2; f.N = L->n; f.ocp = L->ocp;
       f.s_in = s_in; f.s_w = L->s_w; f.s_out = L->s_out; f.zp_out = L->zp_out; f.relu = relu;
-      f.out = dst; f.ob = ob;
+      f.out = dst; f.ob = ob; f.acc = acc;
       I8IE_TRY(i8ie_first_launch(ctx, f));
       if (o_bytes) I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, dst, out, m, cg.kc, cg.oh, cg.ow, 0));
       return I8IE_OK;
@@ -705,7 +710,7 @@ int i8ie_layer_accepts_f32_input(const i8ie_layer* L, int h, int w, int* yes) {
 }
 
 int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, int w, float q_scale, uint8_t q_zp,
-                                 int relu, uint8_t* out, int out_border) {
+                                 int relu, uint8_t* out, int out_border, int32_t* acc) {
   I8IE_REQUIRE(L && in && out, "null argument");
   I8IE_REQUIRE(m > 0 && out_border >= 0, "bad argument");
   int yes = 0;
@@ -717,6 +722,7 @@ int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, i
   i8ie_ctx* ctx = L->ctx;
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
   I8IE_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15u) == 0, "output must be 16-byte aligned");
+  I8IE_REQUIRE(acc == nullptr || aligned16(acc), "accumulator buffer must be 16-byte aligned");
   I8IE_TRY(ensure_offsets(L, q_scale, q_zp));
   ConvGeom cg;
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
@@ -727,7 +733,7 @@ int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, i
   c.KH = cg.kh; c.KW = cg.kw; c.KWG = L->kwg; c.stride = cg.stride; c.pad = cg.pad; c.OH = cg.oh; c.OW = cg.ow;
   c.B = L->Bpack2; c.Kpad = L->Kpad2; c.K2 = L->K2; c.N = L->n; c.ocp = L->ocp;
   c.s_in = q_scale; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
-  c.out = out; c.ob = out_border;
+  c.out = out; c.ob = out_border; c.acc = acc;
   return i8ie_first_launch(ctx, c);
 }
 
@@ -743,8 +749,7 @@ int i8ie_layer_destroy(i8ie_layer* L) {
   i8ie_free(ctx, L->qb);
   i8ie_free(ctx, L->Bpack);
   i8ie_free(ctx, L->Bpack2);
-  if (L->Bpconv) i8ie_free(ctx, L->Bpconv);
-  if (L->Btconv) i8ie_free(ctx, L->Btconv);
+  for (const I8ieWCache::Ent& e : L->wc.ents) i8ie_free(ctx, e.buf);
   i8ie_free(ctx, L->wsum);
   i8ie_free(ctx, L->oc);
   i8ie_free(ctx, L->ocp);

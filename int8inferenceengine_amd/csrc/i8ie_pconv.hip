@@ -36,8 +36,6 @@
 // apart, i8ie_tconv.hip) and the phase stamps behind these statements: DESIGN.md section 4.
 #include <cstdio>
 #include <cstdlib>
-#include <mutex>
-#include <unordered_map>
 #include <type_traits>
 #include <vector>
 
@@ -80,7 +78,8 @@ struct PCArgs {
   int lds_patch, lds_ocp, lds_tab, lds_ktab, lds_src, lds_prog;  // LDS offsets (lds_src < 0: no room for the source table)
   int split;                // 1: a (band, feature pass) pair is a unit of its own (small batches: more units than CUs)
   int flags;                // 1 = weights of the next pass fetched by the last K tile (not with split)
-  unsigned long long* dbg;  // variant 51: per block, cycles spent per phase (wave 0)
+  int32_t* acc;             // ACC kernels: [M][N] pre-requant accumulators (the cblas_gemm_s8u8s32 result, src/conv2d.cc:131-133)
+  unsigned long long* dbg;  // diagnostic build, variant 51: per block, cycles spent per phase (wave 0); null otherwise
 };
 
 #define PC_BAR() asm volatile("s_barrier" ::: "memory")
@@ -109,7 +108,8 @@ __device__ __forceinline__ int pc_row_to_pix(int r) { return (r < 4) ? 2 * r : (
 
 // TMW: 16-pixel MFMA tiles per wave (2 waves along the pixels); NTW: 16-feature tiles per wave (4 waves along the
 // features, block = 64 NTW features per pass)
-template <int TMW, int NTW>
+// ACC: also dump the INT32 accumulators (acc_dbg of the C-ABI) -- a separate instantiation, the default one is untouched
+template <int TMW, int NTW, bool ACC>
 __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   uint8_t* const smem = pc_smem;
   constexpr int BN = NTW * 64;
@@ -246,6 +246,11 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
       for (int ni = 0; ni < NTW; ++ni) {
         const int c4[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
         d[ni] = i8ie_requant_pack4(c4, rq, lo, lof);
+        if constexpr (ACC) {  // row = image-major pixel index (bands are whole rows), 4 consecutive features per lane
+          const int col = n0 + ni * 16 + 4 * lq;
+          if (pi < valid && col < p.N)
+            *reinterpret_cast<v4i*>(p.acc + ((size_t)img * (size_t)(p.OH * p.OW) + (size_t)(oy0 * p.OW + pi)) * (size_t)p.N + col) = acc[mi][ni];
+        }
       }
 #pragma unroll
       for (int ni = 0; ni + 1 < NTW; ni += 2) {
@@ -265,6 +270,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   };
 
   // =============================== tile loop ===========================================================
+#if defined(I8IE_DIAG)
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = 0;
   auto stamp = [&](int i) {
     if (p.dbg) {
@@ -273,6 +279,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
       tq = now;
     }
   };
+#else
+  auto stamp = [](int) {};  // (phase stamps exist in the diagnostic build only: tools/diag)
+#endif
   const int lin_total = p.npass * p.nkt;
   const int patch = p.lds_patch;
   const bool xpre = (p.flags & 1) != 0;  // the last K tile of a pass already fetches the first weights of the next pass / band (+1 %)
@@ -285,7 +294,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
     load_B(Bq[1], 0, 1);
   }
   __syncthreads();
+#if defined(I8IE_DIAG)
   if (p.dbg) tq = __builtin_amdgcn_s_memtime();
+#endif
   for (; unit < t_hi; unit += per) {
     const bool more = unit + per < t_hi;
     const int tile = tile_of(unit);
@@ -350,8 +361,10 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
     stamp(6);  // second barrier
   }
   pc_wait_vm<0>();
+#if defined(I8IE_DIAG)
   if (p.dbg && lane == 0)
     for (int i = 0; i < 7; ++i) p.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
+#endif
 }
 
 // ---- weights in fragment order for this kernel's K walk: [pass][kt][ks][ntile][lane][16] --------------------
@@ -377,24 +390,29 @@ __global__ __launch_bounds__(256) void pconv_pack_kernel(const int8_t* __restric
   }
 }
 
-template <int TMW, int NTW>
-int launch_pc(i8ie_ctx* ctx, const PCArgs& a, int grid, int lds) {
+template <int TMW, int NTW, bool ACC>
+int launch_pc_acc(i8ie_ctx* ctx, const PCArgs& a, int grid, int lds) {
   static bool raised[64] = {};
   const int dev = ctx->device & 63;
   if (!raised[dev]) {
-    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<TMW, NTW>),
+    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<TMW, NTW, ACC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised[dev] = true;
   }
-  pconv_kernel<TMW, NTW><<<grid, 512, lds, ctx->stream>>>(a);
+  pconv_kernel<TMW, NTW, ACC><<<grid, 512, lds, ctx->stream>>>(a);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
+}
+template <int TMW, int NTW>
+int launch_pc(i8ie_ctx* ctx, const PCArgs& a, int grid, int lds) {
+  return a.acc != nullptr ? launch_pc_acc<TMW, NTW, true>(ctx, a, grid, lds) : launch_pc_acc<TMW, NTW, false>(ctx, a, grid, lds);
 }
 
 }  // namespace
 
 int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
-  if (c.amode != 1 || c.acc != nullptr || c.biasf != nullptr || c.wcache == nullptr) return 0;
+  if (c.amode != 1 || c.biasf != nullptr || c.wcache == nullptr) return 0;
+  if (c.acc != nullptr && ((reinterpret_cast<uintptr_t>(c.acc) & 15u) != 0 || c.N % 4 != 0)) return 0;  // (16-byte accumulator stores)
   if (c.N % 16 != 0 || c.N < 192 || c.Npad > 1024 || c.C < 32 || c.C % 32 != 0 || c.sh != c.sw) return 0;
   if ((reinterpret_cast<uintptr_t>(c.out) & 15u) != 0) return 0;
   const int P = c.OH * c.OW;
@@ -508,35 +526,36 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   if (patch_gran * 16 + fixed > 160 * 1024) return 0;
   const bool src_tab = patch_gran * 16 + fixed + patch_gran * 4 <= 160 * 1024;
 
-  // ---- fragment-packed weights (once per layer: the slot lives in the layer handle)
-  // (the slot holds [perm: nkt * 8 ints, padded to 256 B][weights]; re-packed when the pairing key changes)
-  const size_t perm_bytes = i8ie_align_up((size_t)nkt * 8 * sizeof(int), 256);
-  const size_t bf_bytes = (size_t)npass * nkt * kt_bytes;
-  {
-    static std::mutex mu;
-    static std::unordered_map<void*, int> key_of;
-    std::lock_guard<std::mutex> lock(mu);
-    const int key = row_par | (bn << 1);  // (bn: the fragment order depends on the pass width)
-    if (*c.wcache == nullptr || key_of[*c.wcache] != key) {
-      void* buf = *c.wcache;
-      if (buf == nullptr) I8IE_TRY(i8ie_malloc(ctx, perm_bytes + bf_bytes, &buf));
-      I8IE_TRY(i8ie_memcpy_h2d(ctx, buf, perm.data(), perm.size() * sizeof(int)));
-      const int64_t total16 = (int64_t)(bf_bytes / 16);
-      int64_t blocks = (total16 + 255) / 256;
-      if (blocks > 4096) blocks = 4096;
-      pconv_pack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.B, (int8_t*)buf + perm_bytes, total16, c.Kpad, c.Npad, (const int*)buf, nkt, bn);
-      I8IE_LAUNCH_CHECK();
-      *c.wcache = buf;
-      key_of[buf] = key;
-    }
-  }
-
   // One block per CU walks whole bands: with fewer bands than CUs, the passes of a band become units of their own;
   // below 3/4 of the CUs even then, the tiled kernel (finer tiles, two blocks per CU) is the faster one (measured
   // at 125 images: conv3/conv4 0.028/0.038 ms tiled vs 0.035/0.048 ms here) unless the caller forces this kernel.
   const int n_tiles = n_img * bands;
   const int split = (n_tiles < grid && npass > 1) ? 1 : 0;
   if (ctx->variant == 0 && n_tiles * (split ? npass : 1) < grid * 3 / 4) return 0;
+
+  // ---- fragment-packed weights: once per layer and packing key, kept in the layer handle (I8ieWCache)
+  // (a buffer holds [perm: nkt * 8 ints, padded to 256 B][weights]; the fragment order depends on the pass width)
+  const size_t perm_bytes = i8ie_align_up((size_t)nkt * 8 * sizeof(int), 256);
+  const size_t bf_bytes = (size_t)npass * nkt * kt_bytes;
+  const unsigned long long wkey = (1ull << 32) | (unsigned long long)(row_par | (bn << 1));
+  void* wbuf = c.wcache->find(wkey);
+  if (wbuf == nullptr) {
+    I8IE_REQUIRE(ctx->capture == nullptr, "weight re-packing inside a graph capture: run the same calls once eagerly first");
+    I8IE_TRY(i8ie_malloc(ctx, perm_bytes + bf_bytes, &wbuf));
+    int rc = i8ie_memcpy_h2d(ctx, wbuf, perm.data(), perm.size() * sizeof(int));
+    if (rc == I8IE_OK) {
+      const int64_t total16 = (int64_t)(bf_bytes / 16);
+      int64_t blocks = (total16 + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      pconv_pack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.B, (int8_t*)wbuf + perm_bytes, total16, c.Kpad, c.Npad, (const int*)wbuf, nkt, bn);
+      if (hipGetLastError() != hipSuccess) rc = I8IE_ERR_HIP;
+    }
+    if (rc != I8IE_OK) {
+      i8ie_free(ctx, wbuf);
+      return rc;
+    }
+    c.wcache->ents.push_back(I8ieWCache::Ent{wkey, wbuf});
+  }
 
   PCArgs a{};
   a.A = c.A;
@@ -552,8 +571,8 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.patch_gran = patch_gran;
   a.row_gran = row_gran;
   a.rcpRowGran = 1.0f / (float)row_gran;
-  a.Bf = (const int8_t*)*c.wcache + perm_bytes;
-  a.perm = (const int*)*c.wcache;
+  a.Bf = (const int8_t*)wbuf + perm_bytes;
+  a.perm = (const int*)wbuf;
   a.bf_bytes = (unsigned)bf_bytes;
   a.nkt = nkt;
   a.N = c.N; a.npass = npass;
@@ -564,7 +583,11 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.out_bytes = (unsigned)out_bytes;
   a.ob = c.ob; a.OHp = c.OH + 2 * c.ob; a.OWp = c.OW + 2 * c.ob;
   a.split = split;
-  a.flags = (ctx->variant != 53 && !split) ? 1 : 0;  // (variant 53: weights fetched at the start of every pass)
+  a.acc = c.acc;
+  a.flags = !split ? 1 : 0;
+#if defined(I8IE_DIAG)
+  if (ctx->variant == 53) a.flags = 0;  // (weights fetched at the start of every pass)
+#endif
   a.lds_patch = 0;
   a.lds_ocp = patch_gran * 16;
   a.lds_tab = a.lds_ocp + npass * bn * 4;
@@ -580,12 +603,15 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   char nm[32];
   snprintf(nm, sizeof(nm), "pconv_%dx%d", TMW * 32, bn);
   I8ieProfScope prof(ctx, ctx->prof ? tag : nm, ops, bytes);
-  static unsigned long long* dbg_dev = nullptr;
+#if defined(I8IE_DIAG)
+  static unsigned long long* dbg_dev[64] = {};  // per device
+  unsigned long long*& dbg = dbg_dev[ctx->device & 63];
   if (ctx->variant == 51) {
-    if (!dbg_dev) I8IE_HIP_TRY(hipMalloc(&dbg_dev, 4096 * 64 * sizeof(unsigned long long)));
-    I8IE_HIP_TRY(hipMemsetAsync(dbg_dev, 0, 4096 * 64 * sizeof(unsigned long long), ctx->stream));
-    a.dbg = dbg_dev;
+    if (!dbg) I8IE_HIP_TRY(hipMalloc(&dbg, 4096 * 64 * sizeof(unsigned long long)));
+    I8IE_HIP_TRY(hipMemsetAsync(dbg, 0, 4096 * 64 * sizeof(unsigned long long), ctx->stream));
+    a.dbg = dbg;
   }
+#endif
   int rc;
   if (TMW == 8 && bn == 256) rc = launch_pc<8, 4>(ctx, a, grid, lds);
   else if (TMW == 6 && bn == 256) rc = launch_pc<6, 4>(ctx, a, grid, lds);
@@ -593,10 +619,11 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   else if (TMW == 6 && bn == 384) rc = launch_pc<6, 6>(ctx, a, grid, lds);
   else if (TMW == 6 && bn == 128) rc = launch_pc<6, 2>(ctx, a, grid, lds);
   else rc = launch_pc<8, 3>(ctx, a, grid, lds);
+#if defined(I8IE_DIAG)
   if (rc == I8IE_OK && ctx->variant == 51 && std::getenv("I8IE_PCONV_STAMPS") != nullptr) {
     std::vector<unsigned long long> h((size_t)grid * 64);
     I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    I8IE_HIP_TRY(hipMemcpy(h.data(), dbg_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    I8IE_HIP_TRY(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     double sum[8][7] = {};
     for (int b = 0; b < grid; ++b)
       for (int w = 0; w < 8; ++w)
@@ -608,5 +635,6 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     for (int w = 0; w < 8; ++w) fprintf(stderr, " %.0f/%.0f", sum[w][0] / tp, sum[w][2] / tp);
     fprintf(stderr, "\n");
   }
+#endif
   return rc == I8IE_OK ? 1 : rc;
 }

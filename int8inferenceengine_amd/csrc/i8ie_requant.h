@@ -5,14 +5,15 @@
 //     out = q >= 255 ? 255 : (q < 0 ? 0 : (u8)q)                      (IEEE fp32, no contraction)
 // optionally followed by relu<u8> (src/functional.cc:15-26): out = max(out, zp_out).
 //
-// Three evaluation modes, all bit-identical to that sequence:
+// Evaluation modes, all bit-identical to that sequence:
 //   I8IE_RQ_EXACT    the sequence itself.
 //   I8IE_RQ_GUARDED  e = fma((float)C, ms, zp - 0.5), ms = fl(s_in*s_w/s_out), packed with v_cvt_pk_u8_f32
 //                    (round-to-nearest-even, saturate); any dword holding a value closer than 2^-13 to a
 //                    rounding boundary replays the exact sequence (error analysis below).
-//   I8IE_RQ_PROVEN   an estimate of the same form, fma((float)C, ms', bias'), with NO guard: i8ie_requant_fit()
-//                    (below) picks ms', bias' on the host and proves, by finding every step of both step
-//                    functions, that the estimate equals the exact sequence for every int32 C.
+//   I8IE_RQ_PROVEN   (diagnostic build only, -DI8IE_DIAG) an estimate of the same form, fma((float)C, ms', bias'),
+//                    with NO guard: i8ie_requant_fit() picks ms', bias' on the host and proves, by finding every
+//                    step of both step functions, that the estimate equals the exact sequence for every int32 C.
+//                    Measured in round 2: the fit fails on every AlexNet conv layer, so the product keeps the guard.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -50,13 +51,17 @@ __device__ __forceinline__ uint32_t i8ie_requant_pack4(const int (&c)[4], const 
     packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(e, lof), r, packed);
     worst = __builtin_fminf(worst, __builtin_fabsf(__builtin_amdgcn_fractf(e) - 0.5f));
   }
-  if (q.fast == I8IE_RQ_PROVEN || worst >= 1.220703125e-4f) return packed;  // 2^-13 > 9.2e-5, the proven bound
+#if defined(I8IE_DIAG)
+  if (q.fast == I8IE_RQ_PROVEN) return packed;
+#endif
+  if (worst >= 1.220703125e-4f) return packed;  // 2^-13 > 9.2e-5, the proven bound
   packed = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) packed |= (uint32_t)i8ie_requant_exact((float)c[r], q, lo) << (8 * r);
   return packed;
 }
 
+#if defined(I8IE_DIAG)
 // (Measured and dropped: the same estimate two values at a time with v_pk_fma_f32 / v_pk_add_f32 / v_min3_f32,
 // 5.5 instead of 7 instructions per value, made the conv2-5 kernels 8-12 % SLOWER on MI355X: the packed fp32
 // instructions do not issue at the rate of the plain ones next to MFMA waves.  DESIGN.md section 4.)
@@ -70,6 +75,7 @@ __device__ __forceinline__ uint32_t i8ie_requant_pack4_proven(int c0, int c1, in
   packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(__builtin_fmaf((float)c3, ms, bias), lof), 3, packed);
   return packed;
 }
+#endif  // I8IE_DIAG
 #endif
 
 // ---- host side --------------------------------------------------------------------------------------------
@@ -84,6 +90,7 @@ inline I8ieRequant i8ie_make_requant(float s_in, float s_w, float s_out, int zp_
   return r;
 }
 
+#if defined(I8IE_DIAG)
 // ---- proof of the unguarded estimate --------------------------------------------------------------------
 // Both the exact sequence and sat_u8(rne(max(fma(cf, ms, bias), lo))) are non-decreasing step functions of the
 // integer C with values in [lo, 255] (positive scales), so they are equal on every int32 iff they agree at both
@@ -158,3 +165,4 @@ inline bool i8ie_requant_fit(const I8ieRequant& q, int lo, float* ms_out, float*
   }
   return false;
 }
+#endif  // I8IE_DIAG

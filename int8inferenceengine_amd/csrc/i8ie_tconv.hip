@@ -25,8 +25,6 @@
 // Results are those of the other contraction kernels bit for bit (same exact integer sums, same requantiser).
 #include <cstdio>
 #include <cstdlib>
-#include <mutex>
-#include <unordered_map>
 #include <vector>
 
 #include "i8ie_calls.h"
@@ -70,7 +68,8 @@ struct TCArgs {
   unsigned out_bytes;
   int ob, OHp, OWp;
   int lds_ring, lds_ocp, lds_tab, lds_ktab;  // LDS offsets
-  int flags;                                 // timing experiments: 1 = no priority changes, 2 = teams in phase
+  int flags;                                 // timing experiments (diagnostic build): 1 = no priority changes, 2 = teams in phase
+  int32_t* acc;  // ACC kernels: [M][N] pre-requant accumulators (the cblas_gemm_s8u8s32 result, src/conv2d.cc:131-133)
   unsigned long long* dbg;
 };
 
@@ -98,7 +97,8 @@ __device__ __forceinline__ int tc_row_to_pix(int r) { return (r < 4) ? 2 * r : (
 
 // TMW: 16-pixel row tiles per wave (2 waves of a team along the pixels); NTW: 16-feature tiles per wave
 // (2 waves of a team x 2 teams along the features: a pass is 64 NTW features wide)
-template <int TMW, int NTW>
+// ACC: also dump the INT32 accumulators (acc_dbg of the C-ABI) -- a separate instantiation, the default one is untouched
+template <int TMW, int NTW, bool ACC>
 __global__ __launch_bounds__(512, 2) void tconv_kernel(TCArgs p) {
   uint8_t* const smem = tc_smem;
   constexpr int BN = NTW * 64;
@@ -238,6 +238,11 @@ __global__ __launch_bounds__(512, 2) void tconv_kernel(TCArgs p) {
         const v4i c = acc[mi][ni];
         const int cv[4] = {c.x, c.y, c.z, c.w};
         d[ni] = i8ie_requant_pack4(cv, rq, lo, lof);
+        if constexpr (ACC) {  // row = image-major pixel index (bands are whole rows), 4 consecutive features per lane
+          const int col = n0 + ni * 16 + 4 * lq;
+          if (pi < valid && col < p.N)
+            *reinterpret_cast<v4i*>(p.acc + ((size_t)img * (size_t)(p.OH * p.OW) + (size_t)(oy0 * p.OW + pi)) * (size_t)p.N + col) = c;
+        }
       }
 #pragma unroll
       for (int ni = 0; ni + 1 < NTW; ni += 2) {
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void tconv_kernel(TCArgs p) {
     }
   };
 
+#if defined(I8IE_DIAG)
   unsigned long long ph[4] = {0, 0, 0, 0}, tq = 0;
   auto stamp = [&](int i) {
     if (p.dbg) {
@@ -264,6 +270,9 @@ __global__ __launch_bounds__(512, 2) void tconv_kernel(TCArgs p) {
       tq = now;
     }
   };
+#else
+  auto stamp = [](int) {};  // (phase stamps exist in the diagnostic build only: tools/diag)
+#endif
 
   // =============================== segments =============================================================
   // Segment sg of a team = (tile index sg / (2 npass), pass (sg / 2) % npass, K half sg & 1).  In the interval
@@ -275,7 +284,9 @@ __global__ __launch_bounds__(512, 2) void tconv_kernel(TCArgs p) {
   tc_wait_vm0();
   slice_rebias(0);
   __syncthreads();
+#if defined(I8IE_DIAG)
   if (p.dbg) tq = __builtin_amdgcn_s_memtime();
+#endif
   for (int I = 0; I <= segs; ++I) {
     // ---- duty of this interval: the slice with first use in interval I + 1
     int duty_n = -1;
@@ -344,9 +355,11 @@ __global__ __launch_bounds__(512, 2) void tconv_kernel(TCArgs p) {
     stamp(3);  // barrier
   }
   tc_wait_vm0();
+#if defined(I8IE_DIAG)
   if (p.dbg && lane == 0 && (wave == 0 || wave == 4)) {
     for (int i = 0; i < 4; ++i) p.dbg[blockIdx.x * 8 + (wave >> 2) * 4 + i] = ph[i];
   }
+#endif
 }
 
 // ---- weights in fragment order for this kernel's K walk: [pass][kt][ks][ntile][lane][16]; K is ordered
@@ -384,23 +397,28 @@ __global__ __launch_bounds__(256) void tconv_pack_kernel(const int8_t* __restric
   }
 }
 
-template <int TMW, int NTW>
-int launch_tc(i8ie_ctx* ctx, const TCArgs& a, int grid, int lds) {
+template <int TMW, int NTW, bool ACC>
+int launch_tc_acc(i8ie_ctx* ctx, const TCArgs& a, int grid, int lds) {
   static bool raised[64] = {};
   const int dev = ctx->device & 63;
   if (!raised[dev]) {
-    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_kernel<TMW, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv_kernel<TMW, NTW, ACC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised[dev] = true;
   }
-  tconv_kernel<TMW, NTW><<<grid, 512, lds, ctx->stream>>>(a);
+  tconv_kernel<TMW, NTW, ACC><<<grid, 512, lds, ctx->stream>>>(a);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
+}
+template <int TMW, int NTW>
+int launch_tc(i8ie_ctx* ctx, const TCArgs& a, int grid, int lds) {
+  return a.acc != nullptr ? launch_tc_acc<TMW, NTW, true>(ctx, a, grid, lds) : launch_tc_acc<TMW, NTW, false>(ctx, a, grid, lds);
 }
 
 }  // namespace
 
 int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
-  if (c.amode != 1 || c.acc != nullptr || c.biasf != nullptr || c.wcache2 == nullptr) return 0;
+  if (c.amode != 1 || c.biasf != nullptr || c.wcache == nullptr) return 0;
+  if (c.acc != nullptr && ((reinterpret_cast<uintptr_t>(c.acc) & 15u) != 0 || c.N % 4 != 0)) return 0;  // (16-byte accumulator stores)
   if (c.N % 16 != 0 || c.N < 192 || c.Npad > 1024 || c.C < 32 || c.C % 32 != 0 || c.sh != c.sw) return 0;
   if ((reinterpret_cast<uintptr_t>(c.out) & 15u) != 0) return 0;
   const int P = c.OH * c.OW;
@@ -486,7 +504,10 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     // the first K half is the longer one: the wave that goes on to the epilogue leaves the MFMA pipe to the other
     // team's wave earlier (epilogue ~ 5 k cycles ~ 2-3 K tiles of the pair)
     kt_split = (nkt + 1) / 2 + 1;
-    if (const char* e = std::getenv("I8IE_TCONV_SPLIT")) kt_split = std::atoi(e);  // tuning aid
+#if defined(I8IE_DIAG)
+    static const char* const split_env = std::getenv("I8IE_TCONV_SPLIT");  // tuning aid, read once
+    if (split_env) kt_split = std::atoi(split_env);
+#endif
     if (kt_split > nkt - 1) kt_split = nkt - 1;
     if (kt_split < 1) kt_split = 1;
   }
@@ -494,29 +515,30 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   const size_t out_bytes = out_pixels * (size_t)c.N;
   if (out_bytes >= ((size_t)1 << 31) || c.a_bytes >= ((size_t)1 << 32) - 4096) return 0;
 
-  // ---- fragment-packed weights (once per layer: the slot lives in the layer handle)
+  // ---- fragment-packed weights: once per layer and packing key, kept in the layer handle (I8ieWCache)
+  // (a buffer holds [perm: nkt * 8 ints, padded to 256 B][weights])
   const int kt_bytes = bn * 128;
-  // (the slot holds [perm: nkt * 8 ints, padded to 256 B][weights]; re-packed when the pairing key changes)
   const size_t perm_bytes = i8ie_align_up((size_t)nkt * 8 * sizeof(int), 256);
   const size_t bf_bytes = (size_t)npass * nkt * kt_bytes;
-  {
-    static std::mutex mu;
-    static std::unordered_map<void*, int> key_of;
-    std::lock_guard<std::mutex> lock(mu);
-    const int key = row_par | (S << 1) | (bn << 4);
-    if (*c.wcache2 == nullptr || key_of[*c.wcache2] != key) {
-      void* buf = *c.wcache2;
-      if (buf == nullptr) I8IE_TRY(i8ie_malloc(ctx, perm_bytes + bf_bytes, &buf));
-      if (!perm.empty()) I8IE_TRY(i8ie_memcpy_h2d(ctx, buf, perm.data(), perm.size() * sizeof(int)));
+  const unsigned long long wkey = (2ull << 32) | (unsigned long long)(row_par | (S << 1) | (bn << 4));
+  void* wbuf = c.wcache->find(wkey);
+  if (wbuf == nullptr) {
+    I8IE_REQUIRE(ctx->capture == nullptr, "weight re-packing inside a graph capture: run the same calls once eagerly first");
+    I8IE_TRY(i8ie_malloc(ctx, perm_bytes + bf_bytes, &wbuf));
+    int rc = perm.empty() ? I8IE_OK : i8ie_memcpy_h2d(ctx, wbuf, perm.data(), perm.size() * sizeof(int));
+    if (rc == I8IE_OK) {
       const int64_t total16 = (int64_t)(bf_bytes / 16);
       int64_t blocks = (total16 + 255) / 256;
       if (blocks > 4096) blocks = 4096;
-      tconv_pack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.B, (int8_t*)buf + perm_bytes, total16, c.Kpad, c.Npad, CC, CCs, Ks, Ksp, S, nkt, bn,
-                                                               perm.empty() ? nullptr : (const int*)buf);
-      I8IE_LAUNCH_CHECK();
-      *c.wcache2 = buf;
-      key_of[buf] = key;
+      tconv_pack_kernel<<<(int)blocks, 256, 0, ctx->stream>>>(c.B, (int8_t*)wbuf + perm_bytes, total16, c.Kpad, c.Npad, CC, CCs, Ks, Ksp, S, nkt, bn,
+                                                               perm.empty() ? nullptr : (const int*)wbuf);
+      if (hipGetLastError() != hipSuccess) rc = I8IE_ERR_HIP;
     }
+    if (rc != I8IE_OK) {
+      i8ie_free(ctx, wbuf);
+      return rc;
+    }
+    c.wcache->ents.push_back(I8ieWCache::Ent{wkey, wbuf});
   }
 
   TCArgs a{};
@@ -533,9 +555,9 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.slice_gran = slice_gran;
   a.row_gran = row_gran;
   a.rcpRowGran = 1.0f / (float)row_gran;
-  a.perm = perm.empty() ? nullptr : (const int*)*c.wcache2;
+  a.perm = perm.empty() ? nullptr : (const int*)wbuf;
   a.Ks = Ks; a.Ksp = S == 2 ? Ksp : nkt * 8;
-  a.Bf = (const int8_t*)*c.wcache2 + perm_bytes;
+  a.Bf = (const int8_t*)wbuf + perm_bytes;
   a.bf_bytes = (unsigned)bf_bytes;
   a.nkt = nkt; a.kt_split = kt_split;
   a.N = c.N; a.npass = npass;
@@ -545,15 +567,18 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.out = c.out;
   a.out_bytes = (unsigned)out_bytes;
   a.ob = c.ob; a.OHp = c.OH + 2 * c.ob; a.OWp = c.OW + 2 * c.ob;
+  a.acc = c.acc;
   a.lds_ring = 0;
   a.lds_ocp = R * slice_gran * 16;
   a.lds_tab = a.lds_ocp + npass * bn * 4;
   a.lds_ktab = a.lds_tab + 2 * kTabPix * 4;
   const int lds = a.lds_ktab + nkt * 32;
+#if defined(I8IE_DIAG)
   if (ctx->variant == 72) a.flags = 1;
   if (ctx->variant == 73) a.flags = 2;
   if (ctx->variant == 74) a.flags = 3;
   if (ctx->variant == 75) a.flags = 4;
+#endif
 
   const double ops = 2.0 * c.M * c.N * c.Ktrue;
   const double bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
@@ -562,22 +587,26 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   char nm[32];
   snprintf(nm, sizeof(nm), "tconv_%dx%d", TMW * 32, bn);
   I8ieProfScope prof(ctx, ctx->prof ? tag : nm, ops, bytes);
-  static unsigned long long* dbg_dev = nullptr;
+#if defined(I8IE_DIAG)
+  static unsigned long long* dbg_dev[64] = {};  // per device
+  unsigned long long*& dbg = dbg_dev[ctx->device & 63];
   const bool stamps = ctx->variant >= 71 && ctx->variant <= 74;
   if (stamps) {
-    if (!dbg_dev) I8IE_HIP_TRY(hipMalloc(&dbg_dev, 4096 * 8 * sizeof(unsigned long long)));
-    I8IE_HIP_TRY(hipMemsetAsync(dbg_dev, 0, 4096 * 8 * sizeof(unsigned long long), ctx->stream));
-    a.dbg = dbg_dev;
+    if (!dbg) I8IE_HIP_TRY(hipMalloc(&dbg, 4096 * 8 * sizeof(unsigned long long)));
+    I8IE_HIP_TRY(hipMemsetAsync(dbg, 0, 4096 * 8 * sizeof(unsigned long long), ctx->stream));
+    a.dbg = dbg;
   }
+#endif
   int rc;
   if (TMW == 8 && bn == 256) rc = launch_tc<8, 4>(ctx, a, grid, lds);
   else if (TMW == 6 && bn == 256) rc = launch_tc<6, 4>(ctx, a, grid, lds);
   else if (TMW == 6 && bn == 192) rc = launch_tc<6, 3>(ctx, a, grid, lds);
   else rc = launch_tc<8, 3>(ctx, a, grid, lds);
+#if defined(I8IE_DIAG)
   if (rc == I8IE_OK && stamps && std::getenv("I8IE_TCONV_STAMPS") != nullptr) {
     std::vector<unsigned long long> h((size_t)grid * 8);
     I8IE_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    I8IE_HIP_TRY(hipMemcpy(h.data(), dbg_dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    I8IE_HIP_TRY(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     double sum[2][4] = {};
     for (int b = 0; b < grid; ++b)
       for (int t = 0; t < 2; ++t)
@@ -588,5 +617,6 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
               ctx->variant, t, c.M, c.N, c.Kchunks * 16, a.n_tiles, npass, nkt, kt_split, TMW, bn, S, R, sum[t][0] / tp, sum[t][0] / tp / nkt,
               sum[t][1] / tp, sum[t][2] / tp, sum[t][3] / tp);
   }
+#endif
   return rc == I8IE_OK ? 1 : rc;
 }

@@ -198,7 +198,9 @@ struct Storage {
       event_put(ready_ev);
       ready_ev = nullptr;
     }
-    if (upload_block) {
+    int capturing = 0;  // a graph being captured has this address baked in: the block goes to the graph
+    i8ie_ctx_is_capturing(rt().ctx, &capturing);  // (i8ie_free hands it over), never to a cache of ours
+    if (upload_block && !capturing) {
       auto& slot = upload_cache()[bytes];
       if (slot.size() < 4) {
         i8ie_event* e = event_take();
@@ -207,7 +209,7 @@ struct Storage {
         return;
       }
     }
-    if (bzp >= 0 && layout == I8IE_LAYOUT_NHWC && border > 0) {
+    if (bzp >= 0 && layout == I8IE_LAYOUT_NHWC && border > 0 && !capturing) {
       auto& slot = border_cache()[BorderKey{bytes, dn, dc, dh, dw, border, bzp}];
       if (slot.size() < 4) {
         slot.push_back(dev);
@@ -920,7 +922,7 @@ class BaseLayer {
             if (yes) {  // quantize + conv (+ relu) in one kernel, reading the FP32 input
               auto st = nhwc_storage(oshp, border, zp_out);
               check(i8ie_layer_forward_f32_input(handle.get(), (const float*)src.qsrc->device_ptr(), m, h, w,
-                                                 src.qscale, src.qzp, relu ? 1 : 0, (uint8_t*)st->dev, border));
+                                                 src.qscale, src.qzp, relu ? 1 : 0, (uint8_t*)st->dev, border, nullptr));
               return st;
             }
           }
@@ -1341,6 +1343,10 @@ PYBIND11_MODULE(_CXX_i8ie, m) {
   m.def("upload_into", [](Tensor<float>& t, py::array_t<float, py::array::c_style | py::array::forcecast> a) {
     if ((size_t)a.size() != (size_t)t.size) throw std::invalid_argument("upload_into: size mismatch");
     check(i8ie_memcpy_h2d(ctx(), t.dptr(), a.data(), (size_t)t.size * 4));
+    if (t.st) {  // a host mirror of the old values (small tensors made from an ndarray) is stale now
+      t.st->host_valid = false;
+      std::vector<unsigned char>().swap(t.st->host);
+    }
   });
 
   // raw device copy into / out of foreign HIP memory (e.g. a torch tensor's data_ptr) for the

@@ -21,6 +21,7 @@ import _CXX_i8ie as cx
 class GraphedForward:
     def __init__(self, forward, x):
         self.x = x
+        self.forward = forward  # the graph replays kernels that read the layers' device weights: keep them alive
         y = forward(x)          # eager: creates every lazily built cache, sizes the workspace
         y.data.prefetch()
         cx.synchronize()

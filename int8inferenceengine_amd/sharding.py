@@ -82,9 +82,14 @@ class ShardedRunner:
     gathered logits as an ndarray on rank 0 (None elsewhere).  Submitting batch i + 1 before asking for batch i's
     result is the depth-2 pipeline bench.py times.  Every rank must make the same sequence of submit() calls
     (each contains a collective).
+
+    `depth` (default 2) is the number of batches that may be outstanding (submitted, result() not yet taken): the
+    stage / receive / pinned buffers are rings of that many slots.  A submit() that would reuse the slot of a batch
+    whose result has not been collected raises RuntimeError instead of overwriting it, and result() refuses a handle
+    whose slot has since been handed to another batch (on every rank, also where result() returns None).
     """
 
-    def __init__(self, forward, n_total, n_classes, rank=None, world=None, host_copies=False, group=None):
+    def __init__(self, forward, n_total, n_classes, rank=None, world=None, host_copies=False, group=None, depth=2):
         import torch.distributed as dist
 
         self.forward = forward
@@ -95,7 +100,11 @@ class ShardedRunner:
         self.world = dist.get_world_size(group) if world is None else int(world)
         self.start, self.stop = shard_bounds(self.n_total, self.rank, self.world)
         self.host_copies = bool(host_copies)
+        self.depth = int(depth)
+        if self.depth < 1:
+            raise ValueError("ShardedRunner: depth must be >= 1")
         self._tick = 0
+        self._owner = [None] * self.depth  # tick of the uncollected batch that occupies slot k, or None
         self._stage = None
 
     # ---- which images are mine ---------------------------------------------------------------------------
@@ -112,34 +121,52 @@ class ShardedRunner:
         import torch
 
         self._torch = torch
-        self._stage = [torch.empty((self.rows, self.n_classes), dtype=torch.float32, device="cuda") for _ in range(2)]
+        D = self.depth
+        self._stage = [torch.empty((self.rows, self.n_classes), dtype=torch.float32, device="cuda") for _ in range(D)]
         self._side = torch.cuda.Stream()
-        self._gathered = [None, None]
+        self._gathered = [None] * D
         # equal shards: the gather's receive buffers are allocated once (no allocator traffic per batch)
         self._even = self.n_total % self.world == 0
-        self._recv = [torch.empty((self.n_total, self.n_classes), dtype=torch.float32, device="cuda") for _ in range(2)] if self._even else None
+        self._recv = [torch.empty((self.n_total, self.n_classes), dtype=torch.float32, device="cuda") for _ in range(D)] if self._even else None
         self._host = None
         if self.rank == 0:
-            self._host = [torch.empty((self.n_total, self.n_classes), dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._host = [torch.empty((self.n_total, self.n_classes), dtype=torch.float32).pin_memory() for _ in range(D)]
+
+    def _claim_slot(self):
+        tick = self._tick
+        k = tick % self.depth
+        if self._owner[k] is not None:
+            raise RuntimeError("ShardedRunner: batch %d would overwrite the buffers of batch %d, whose result() has not "
+                               "been taken (depth=%d: at most that many batches may be outstanding)"
+                               % (tick, self._owner[k], self.depth))
+        self._owner[k] = tick
+        self._tick += 1
+        return k, tick
+
+    def _release_slot(self, k, tick):
+        if self._owner[k] != tick:
+            raise RuntimeError("ShardedRunner: stale handle (batch %d): its result was already taken or its slot reused"
+                               % tick)
+        self._owner[k] = None
 
     def submit(self, x):
+        # (claimed before the forward: a refused submit must not have issued this rank's part of a collective)
+        k, tick = self._claim_slot()
         y = self.forward(x)
         if self.host_copies:
             import torch
 
             local = y.numpy() if hasattr(y, "numpy") and not isinstance(y, np.ndarray) else np.asarray(y)
             full = gather_rows(torch.from_numpy(np.ascontiguousarray(local, np.float32)), self.n_total, self.group)
-            return ("host", full.numpy() if self.rank == 0 else None)
+            return ("host", k, tick, full.numpy() if self.rank == 0 else None)
         if self._stage is None:
             self._device_setup()
         import _CXX_i8ie as cx
 
         torch = self._torch
-        k = self._tick & 1
-        self._tick += 1
         main = torch.cuda.current_stream()
         if self._gathered[k] is not None:
-            main.wait_event(self._gathered[k])  # the gather of two batches ago has finished reading stage[k]
+            main.wait_event(self._gathered[k])  # the gather of `depth` batches ago has finished reading stage[k]
         cx.copy_to_ptr(y.data, self._stage[k].data_ptr())
         ready = torch.cuda.Event()
         ready.record(main)
@@ -157,16 +184,17 @@ class ShardedRunner:
             ev = torch.cuda.Event()
             ev.record(self._side)
         self._gathered[k] = ev
-        return ("dev", k, ev)
+        return ("dev", k, tick, ev)
 
     def result(self, handle):
-        if handle[0] == "host":
-            return handle[1]
-        _, k, ev = handle
+        kind, k, tick, payload = handle
+        self._release_slot(k, tick)
+        if kind == "host":
+            return payload
         if self.rank != 0:
             return None
-        ev.synchronize()
-        return self._host[k].numpy().copy()
+        payload.synchronize()
+        return self._host[k].numpy().copy()  # (copied out: the pinned slot is free for the next batch)
 
     def run(self, x):
         """submit + result: one batch, no pipelining."""

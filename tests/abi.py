@@ -8,7 +8,8 @@ import re
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "int8inferenceengine_amd", "libi8ie_hip.so")
+# ($I8IE_LIB: another build of the same C-ABI, e.g. the diagnostic build of tools/diag)
+LIB_PATH = os.environ.get("I8IE_LIB") or os.path.join(ROOT, "int8inferenceengine_amd", "libi8ie_hip.so")
 HEADER = os.path.join(ROOT, "include", "i8ie_hip.h")
 
 _lib = None

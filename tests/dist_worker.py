@@ -53,6 +53,29 @@ def main():
         else:
             assert o is None
     assert (runner.run(runner.shard(batches[0])) is None) == (rank != 0)
+    # the depth contract is enforced: a third outstanding batch at depth 2 is refused BEFORE it issues a collective
+    # (every rank refuses alike, so the group stays matched), a collected handle cannot be read twice, and a deeper
+    # ring (depth 3) takes three outstanding batches and returns each one's own logits
+    h0 = runner.submit(runner.shard(batches[0]))
+    h1 = runner.submit(runner.shard(batches[1]))
+    try:
+        runner.submit(runner.shard(batches[2]))
+        raise AssertionError("a third outstanding batch at depth 2 must be refused")
+    except RuntimeError as e:
+        assert "outstanding" in str(e)
+    r0, r1 = runner.result(h0), runner.result(h1)
+    if rank == 0:
+        assert np.array_equal(r0, net(batches[0])) and np.array_equal(r1, net(batches[1]))
+    try:
+        runner.result(h0)
+        raise AssertionError("a handle must not be readable twice")
+    except RuntimeError as e:
+        assert "stale handle" in str(e)
+    deep = sharding.ShardedRunner(net, n_total, 10, host_copies=True, depth=3)
+    hs = [deep.submit(deep.shard(xb)) for xb in batches]
+    for xb, h in zip(batches, hs):
+        o = deep.result(h)
+        assert (o is None) if rank != 0 else np.array_equal(o, net(xb))
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d/%d ok rows [%d,%d)" % (rank, world, start, stop))

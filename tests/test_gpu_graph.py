@@ -40,6 +40,34 @@ def test_graph_replay_matches_eager_forward(env, name, batch):
     assert np.array_equal(g().numpy(), want_a)
 
 
+def test_replay_survives_an_eager_forward_at_another_batch_size(env):
+    """A graph captured at 125 images (the 8-GPU shard: conv5 as two passes of 128, conv3/4 two of 192) keeps
+    replaying correctly after an eager forward at 1000 images, which packs the weights of the same layers for wider
+    passes (256 / 384), needs a larger workspace (the grouped first-layer image) and recycles bordered blocks: the
+    packed weights live per packing key in the layer handle, the workspace the graph was captured with stays
+    allocated, and a GraphedForward keeps its network alive."""
+    import gc
+    cx, i8ie, wl, GraphedForward = env
+    xs = wl.synthetic_input("alexnet", 125, seed=21)
+    xl = wl.synthetic_input("alexnet", 1000, seed=22)
+
+    def make():
+        net = wl.calibrated("alexnet", wl.synthetic_state_dict("alexnet", seed=5))
+        want = net(i8ie.tensor(xs)).numpy()
+        return GraphedForward(net, i8ie.tensor(xs).prefetch()), want  # the only reference to `net` is the graph's
+
+    g, want_s = make()
+    gc.collect()
+    assert np.array_equal(g().numpy(), want_s)
+    want_l = g.forward(i8ie.tensor(xl)).numpy()          # eager, 8 x the batch: new packing keys, workspace growth
+    assert np.array_equal(g().numpy(), want_s)           # replay: its own weights, its own workspace
+    assert np.array_equal(g.forward(i8ie.tensor(xl)).numpy(), want_l)
+    assert np.array_equal(want_l[:5], g.forward(i8ie.tensor(xl[:5])).numpy())  # (batch invariance of the rows)
+    g.load(xs[::-1].copy())
+    assert np.array_equal(g().numpy(), want_s[::-1])
+    assert np.array_equal(g.x.numpy(), xs[::-1])         # load() leaves no stale host mirror behind
+
+
 def test_graph_logits_match_the_oracle(env, orc):
     import pipeline
     cx, i8ie, wl, GraphedForward = env

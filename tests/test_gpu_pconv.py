@@ -1,5 +1,5 @@
 """The patch-stationary convolution kernels (csrc/i8ie_pconv.hip: variants 50 and 54 (N = 384 as two passes of 192 instead of one of 384); csrc/i8ie_tconv.hip: variant 70)
-against the oracle, through the C-ABI.
+against the oracle, through the C-ABI: u8 outputs AND the INT32 pre-requant accumulators (acc_dbg).
 
 Every output byte of the whole batch is compared.  Geometries hit: one feature pass of 256, two passes of 192
 (N = 384), two passes of 256 with the second partly empty (N = 320), one pass of 192; row tiles 11 (one ghost
@@ -77,14 +77,16 @@ def test_pconv_bit_exact(gpu, orc, geom, relu, ob, VARIANT):
         try:
             return gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
                                            cs["s_out"], cs["zp_out"], stride=stride, pad=pad, in_nhwc=True,
-                                           out_nhwc=True, relu=relu, in_border=pad, out_border=ob, want_acc=False)
+                                           out_nhwc=True, relu=relu, in_border=pad, out_border=ob, want_acc=True)
         finally:
             abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
 
-    (out, _, _), names = _kernels_run(gpu, run)  # (the harness also checks that border bytes stay zp_out)
+    (out, acc, _), names = _kernels_run(gpu, run)  # (the harness also checks that border bytes stay zp_out)
     if not (VARIANT == 70 and k * k * c < 512):  # (the team kernel leaves K < 4 K tiles to the others)
         assert any(nm.startswith(VARIANTS[VARIANT]) for nm in names), names
     want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
+    # the INT32 pre-requant accumulators of the kernel under test (the cblas_gemm_s8u8s32 result, src/conv2d.cc:131-133)
+    assert np.array_equal(acc, cs["acc"])
     assert np.array_equal(out, want)
 
 
@@ -99,9 +101,11 @@ def test_pconv_wider_input_border_than_padding(gpu, orc, VARIANT):
     try:
         out = gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
                                       cs["s_out"], cs["zp_out"], stride=1, pad=1, in_nhwc=True, out_nhwc=True,
-                                      in_border=2, out_border=0, want_acc=False)[0]
+                                      in_border=2, out_border=0, want_acc=True)[:2]
     finally:
         abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
+    out, acc = out
+    assert np.array_equal(acc, cs["acc"])
     assert np.array_equal(out, cs["out"])
 
 
@@ -114,12 +118,14 @@ def test_pconv_extreme_operands(gpu, orc, VARIANT):
     qw = np.where(rng.random((kc, c, k, k)) < 0.5, 127, -128).astype(np.int8)
     qb = rng.integers(-128, 128, kc).astype(np.int8)
     s_in, zp_in, s_w, s_out, zp_out = 0.02, 3, 0.004, 0.9, 131
-    want = orc.conv2d(q_in, qw, qb, 1, 1, np.float32(s_in), zp_in, np.float32(s_w), np.float32(s_out), zp_out)[0]
+    want, want_acc = orc.conv2d(q_in, qw, qb, 1, 1, np.float32(s_in), zp_in, np.float32(s_w), np.float32(s_out), zp_out,
+                                want_acc=True)
     lib = abi.lib()
     abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, VARIANT))
     try:
-        out = gpu.layer_forward_fused("conv", q_in, qw, qb, s_in, zp_in, s_w, s_out, zp_out, stride=1, pad=1,
-                                      in_nhwc=True, out_nhwc=True, in_border=1, want_acc=False)[0]
+        out, acc = gpu.layer_forward_fused("conv", q_in, qw, qb, s_in, zp_in, s_w, s_out, zp_out, stride=1, pad=1,
+                                           in_nhwc=True, out_nhwc=True, in_border=1, want_acc=True)[:2]
     finally:
         abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
+    assert np.array_equal(acc, want_acc)
     assert np.array_equal(out, want)

@@ -54,9 +54,11 @@ def test_random_geometry(gpu, orc, case):
     for variant in (0, 50, 70):
         abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, variant))
         try:
-            out = gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
-                                          cs["s_out"], cs["zp_out"], stride=stride, pad=pad, in_nhwc=True, out_nhwc=True,
-                                          relu=relu, in_border=pad + extra, out_border=ob, want_acc=False)[0]
+            out, acc = gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],
+                                               cs["s_out"], cs["zp_out"], stride=stride, pad=pad, in_nhwc=True,
+                                               out_nhwc=True, relu=relu, in_border=pad + extra, out_border=ob,
+                                               want_acc=True)[:2]
         finally:
             abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
+        assert np.array_equal(acc, cs["acc"]), (variant, case)  # INT32 pre-requant accumulators (src/conv2d.cc:131-133)
         assert np.array_equal(out, want), (variant, case)

@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "i8ie_calls.h"
+#include "i8ie_diag.h"
 #include "i8ie_internal.h"
 #include "i8ie_requant.h"
 
