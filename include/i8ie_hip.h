@@ -281,6 +281,18 @@ int i8ie_layer_forward_fused(i8ie_layer* layer, const uint8_t* in_dev, int in_la
                              int h, int w, float s_in, uint8_t zp_in, int relu, uint8_t* out_dev,
                              int out_layout, int out_border, int32_t* acc_dbg_dev);
 int i8ie_layer_preferred_layout(const i8ie_layer* layer, int* layout);
+/* relu(conv(x)) followed by max_pool2d<u8_t>(., kernel_size, stride) (src/functional.cc:36-64; the reference's models
+ * call it right behind conv1 / conv2 / conv5, sample/notebooks/AlexNet_cifar10_resize224.ipynb:60-68) as ONE call:
+ * out holds the POOLED tensor, [m, kc, (oh - k)/s + 1, (ow - k)/s + 1] in out_layout.  Where a kernel of this library
+ * folds the pool into the convolution's epilogue (i8ie_layer_fuses_pool says so: it then pools the INT32
+ * accumulators before requantising them -- down_scale and relu are monotone in C, so the bytes are those of
+ * pooling afterwards), no unpooled tensor is ever written; otherwise the call runs the convolution into a
+ * temporary and the max-pool kernel behind it.  Identical bytes to i8ie_layer_forward_fused followed by
+ * i8ie_maxpool2d_u8(_nhwc) either way.  acc_dbg_dev: the convolution's (unpooled) accumulators [m, oh*ow, kc]. */
+int i8ie_layer_fuses_pool(const i8ie_layer* layer, int h, int w, int kernel_size, int stride, int* yes);
+int i8ie_layer_forward_pool(i8ie_layer* layer, const uint8_t* in_dev, int in_layout, int in_border, int m, int h, int w,
+                            float s_in, uint8_t zp_in, int relu, int kernel_size, int stride, uint8_t* out_dev,
+                            int out_layout, int out_border, int32_t* acc_dbg_dev);
 /* First layer fused with the input quantisation (Module.__call__ quantises the FP32 input with
  * 0.025 / 127, i8ie/module.py:20, and hands it straight to the first Conv2d): reads FP32 NCHW,
  * computes q = (u8)(x / q_scale + q_zp) exactly as src/quantize_utils.cc:44-52 and the conv of
@@ -292,6 +304,11 @@ int i8ie_layer_preferred_layout(const i8ie_layer* layer, int* layout);
 int i8ie_layer_accepts_f32_input(const i8ie_layer* layer, int h, int w, int* yes);
 int i8ie_layer_forward_f32_input(i8ie_layer* layer, const float* in_nchw_dev, int m, int h, int w, float q_scale,
                                  uint8_t q_zp, int relu, uint8_t* out_nhwc_dev, int out_border, int32_t* acc_dbg_dev);
+/* the same with max_pool2d<u8_t>(kernel_size, stride) behind the (relu'd) convolution, as in i8ie_layer_forward_pool:
+ * quantize -> conv1 -> relu -> max-pool of AlexNet in one contraction launch (csrc/i8ie_stem.hip) */
+int i8ie_layer_forward_f32_input_pool(i8ie_layer* layer, const float* in_nchw_dev, int m, int h, int w, float q_scale,
+                                      uint8_t q_zp, int relu, int kernel_size, int stride, uint8_t* out_nhwc_dev,
+                                      int out_border, int32_t* acc_dbg_dev);
 /* padding of a conv layer (0 for Linear): the input border that makes its gather predicate-free */
 int i8ie_layer_padding(const i8ie_layer* layer, int* pad);
 int i8ie_layer_destroy(i8ie_layer* layer);

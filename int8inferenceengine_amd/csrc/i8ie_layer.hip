@@ -18,6 +18,7 @@
 
 #include "i8ie_internal.h"
 #include "i8ie_calls.h"
+#include "i8ie_stem.h"
 
 int i8ie_launch_pad_rows(i8ie_ctx* ctx, const void* src, int rows, int k, void* dst, int rows_pad, int k_pad,
                          int fill);
@@ -197,6 +198,8 @@ struct i8ie_layer {
   I8ieWCache wc;            // Bpack2 in the fragment orders of i8ie_pconv.hip / i8ie_tconv.hip: one buffer per packing
                             // key, made on first use, never overwritten (captured graphs replay their addresses)
   int kwg = 0;              // path B: taps per row in 4-pixel groups
+  int8_t* Bstem = nullptr;  // path B, when the first-stage kernel (i8ie_stem.hip) takes the layer: [n][KpadStem], K in its
+  int KpadStem = 0;         // space-to-depth order (i8ie_stem_kindex), zero padded
   int32_t* wsum = nullptr;  // [n]
   int32_t* oc = nullptr;    // [n], valid for (oc_s_in, oc_zp_in)
   int32_t* ocp = nullptr;   // [n] oc + 128 * wsum
@@ -380,6 +383,16 @@ static int layer_create(i8ie_ctx* ctx, bool conv, const int8_t* qw_host, const i
             pack2[(size_t)j * L->Kpad2 + ((size_t)y * L->kwg + x / 4) * 16 + (x % 4) * 4 + ch] =
                 qw_host[(((size_t)j * c + ch) * kh + y) * kw + x];
   }
+  std::vector<int8_t> packs;  // the same weights in the K order of the first-stage kernel (i8ie_stem.hip)
+  if (L->path == PATH_B && c <= 3 && n % 32 == 0 && n <= 96 && (kh + 3) / 4 * ((kw + 3) / 4) * 48 <= 14 * 32) {
+    L->KpadStem = i8ie_stem_kpad(kh, kw);
+    packs.assign((size_t)n * L->KpadStem, 0);
+    for (int j = 0; j < n; ++j)
+      for (int ch = 0; ch < c; ++ch)
+        for (int y = 0; y < kh; ++y)
+          for (int x = 0; x < kw; ++x)
+            packs[(size_t)j * L->KpadStem + i8ie_stem_kindex(kw, ch, y, x)] = qw_host[(((size_t)j * c + ch) * kh + y) * kw + x];
+  }
   int rc = I8IE_OK;
   do {
     if ((rc = i8ie_malloc(ctx, (size_t)n * K, (void**)&L->qw)) != I8IE_OK) break;
@@ -398,6 +411,10 @@ static int layer_create(i8ie_ctx* ctx, bool conv, const int8_t* qw_host, const i
     if (!pack2.empty()) {
       if ((rc = i8ie_malloc(ctx, pack2.size(), (void**)&L->Bpack2)) != I8IE_OK) break;
       if ((rc = i8ie_memcpy_h2d(ctx, L->Bpack2, pack2.data(), pack2.size())) != I8IE_OK) break;
+    }
+    if (!packs.empty()) {
+      if ((rc = i8ie_malloc(ctx, packs.size(), (void**)&L->Bstem)) != I8IE_OK) break;
+      if ((rc = i8ie_memcpy_h2d(ctx, L->Bstem, packs.data(), packs.size())) != I8IE_OK) break;
     }
   } while (0);
   if (rc != I8IE_OK) {
@@ -449,15 +466,25 @@ int i8ie_layer_padding(const i8ie_layer* L, int* pad) {
 }
 
 static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, int in_border, int m, int h, int w,
-                              float s_in, uint8_t zp_in, int relu, uint8_t* out, int out_layout, int out_border,
-                              int32_t* acc, float* out_f32);
+                              float s_in, uint8_t zp_in, int relu, int pool_k, int pool_s, uint8_t* out, int out_layout,
+                              int out_border, int32_t* acc, float* out_f32);
 
 int i8ie_layer_forward_fused(i8ie_layer* L, const uint8_t* in, int in_layout, int in_border, int m, int h, int w,
                              float s_in, uint8_t zp_in, int relu, uint8_t* out, int out_layout, int out_border,
                              int32_t* acc) {
   I8IE_REQUIRE(out != nullptr, "null argument");
-  return layer_forward_impl(L, in, in_layout, in_border, m, h, w, s_in, zp_in, relu, out, out_layout, out_border, acc,
-                            nullptr);
+  return layer_forward_impl(L, in, in_layout, in_border, m, h, w, s_in, zp_in, relu, 0, 0, out, out_layout, out_border,
+                            acc, nullptr);
+}
+
+int i8ie_layer_forward_pool(i8ie_layer* L, const uint8_t* in, int in_layout, int in_border, int m, int h, int w,
+                            float s_in, uint8_t zp_in, int relu, int pool_k, int pool_s, uint8_t* out, int out_layout,
+                            int out_border, int32_t* acc) {
+  I8IE_REQUIRE(L != nullptr && out != nullptr, "null argument");
+  I8IE_REQUIRE(L->conv, "i8ie_layer_forward_pool: Conv2d layers only");
+  I8IE_REQUIRE(pool_k > 0 && pool_s > 0, "kernel_size and stride must be positive");
+  return layer_forward_impl(L, in, in_layout, in_border, m, h, w, s_in, zp_in, relu, pool_k, pool_s, out, out_layout,
+                            out_border, acc, nullptr);
 }
 
 // dequantize(layer(x)) for a Linear layer: src/quantize_utils.cc:54-58 applied to the result of
@@ -467,13 +494,19 @@ int i8ie_layer_forward_dequant(i8ie_layer* L, const uint8_t* in, int in_layout, 
                                uint8_t zp_in, int relu, uint8_t* out_u8, float* out_f32) {
   I8IE_REQUIRE(L && out_f32, "null argument");
   I8IE_REQUIRE(!L->conv, "i8ie_layer_forward_dequant: Linear layers only");
-  return layer_forward_impl(L, in, in_layout, 0, m, h, w, s_in, zp_in, relu, out_u8, I8IE_LAYOUT_NCHW, 0, nullptr,
+  return layer_forward_impl(L, in, in_layout, 0, m, h, w, s_in, zp_in, relu, 0, 0, out_u8, I8IE_LAYOUT_NCHW, 0, nullptr,
                             out_f32);
 }
 
+// the first-stage kernel (i8ie_stem.hip) takes this conv layer at this output size (+ this pool behind it)?
+static bool stem_takes(const i8ie_layer* L, const ConvGeom& cg, int pool_k, int pool_s) {
+  return L->conv && L->path == PATH_B && L->Bstem != nullptr && !force_fallback(L->ctx) && L->ctx->variant != 11 &&
+         i8ie_stem_supported(cg.c, cg.stride, L->n, cg.kh, cg.kw, cg.oh, cg.ow, pool_k, pool_s) != 0;
+}
+
 static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, int in_border, int m, int h, int w,
-                              float s_in, uint8_t zp_in, int relu, uint8_t* out, int out_layout, int out_border,
-                              int32_t* acc, float* out_f32) {
+                              float s_in, uint8_t zp_in, int relu, int pool_k, int pool_s, uint8_t* out, int out_layout,
+                              int out_border, int32_t* acc, float* out_f32) {
   I8IE_REQUIRE(L && in, "null argument");
   I8IE_REQUIRE(out != nullptr || (out_f32 != nullptr && !L->conv), "null output");
   I8IE_REQUIRE(m > 0, "non-positive batch");
@@ -502,7 +535,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
         I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)m * L->K + (size_t)m * L->Kpad + (size_t)8 * m * L->n * 4 + 4096));
         uint8_t* t = (uint8_t*)ctx->ws + i8ie_align_up((size_t)m * L->Kpad + (size_t)8 * m * L->n * 4, 256) + 512;
         I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, in, t, m, L->K / hw, h, w, 0));
-        return layer_forward_impl(L, t, I8IE_LAYOUT_NCHW, 0, m, 0, 0, s_in, zp_in, relu, out, out_layout, out_border,
+        return layer_forward_impl(L, t, I8IE_LAYOUT_NCHW, 0, m, 0, 0, s_in, zp_in, relu, 0, 0, out, out_layout, out_border,
                                   acc, out_f32);
       }
       if (L->Bperm == nullptr || L->perm_c != L->K / hw || L->perm_hw != hw) {
@@ -525,7 +558,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
     }
     I8IE_REQUIRE(out != nullptr, "i8ie_layer_forward_dequant: this layer needs the u8 output buffer as well");
     if (out_f32 != nullptr) {  // general shape: the ordinary forward, then the dequantize kernel
-      I8IE_TRY(layer_forward_impl(L, in, in_layout, 0, m, h, w, s_in, zp_in, relu, out, I8IE_LAYOUT_NCHW, 0, acc, nullptr));
+      I8IE_TRY(layer_forward_impl(L, in, in_layout, 0, m, h, w, s_in, zp_in, relu, 0, 0, out, I8IE_LAYOUT_NCHW, 0, acc, nullptr));
       return i8ie_dequantize_u8_f32(ctx, out, out_f32, (int64_t)m * L->n, L->s_out, L->zp_out);
     }
 #if defined(I8IE_DIAG)
@@ -597,8 +630,37 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
   // ---- Conv2d --------------------------------------------------------------------------------
   ConvGeom cg;
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
+  const bool pool = pool_k > 1 || (pool_k == 1 && pool_s > 1);
+  if (pool) {
+    I8IE_REQUIRE(pool_k <= cg.oh && pool_k <= cg.ow, "max-pool window larger than the convolution's output");
+    if (!stem_takes(L, cg, pool_k, pool_s)) {
+      // no kernel fuses this pool: max_pool2d<u8> (src/functional.cc:36-64) as its own launch behind the convolution
+      const int ph = (cg.oh - pool_k) / pool_s + 1, pw = (cg.ow - pool_k) / pool_s + 1;
+      const bool nhwc = out_layout == I8IE_LAYOUT_NHWC && L->n % 16 == 0;
+      uint8_t* tmp = nullptr;
+      I8IE_TRY(i8ie_malloc(ctx, (size_t)m * L->n * cg.oh * cg.ow, (void**)&tmp));
+      int rc = layer_forward_impl(L, in, in_layout, in_border, m, h, w, s_in, zp_in, relu, 0, 0, tmp,
+                                  nhwc ? I8IE_LAYOUT_NHWC : I8IE_LAYOUT_NCHW, 0, acc, nullptr);
+      if (rc == I8IE_OK) {
+        if (nhwc) {
+          rc = i8ie_launch_maxpool_nhwc(ctx, tmp, 0, out, out_border, m, L->n, cg.oh, cg.ow, pool_k, pool_s, 0);
+        } else if (out_layout == I8IE_LAYOUT_NCHW) {
+          rc = i8ie_maxpool2d_u8(ctx, tmp, out, m, L->n, cg.oh, cg.ow, pool_k, pool_s);
+        } else {  // NHWC result with channels % 16 != 0: pool in NCHW, then lay out
+          uint8_t* tmp2 = nullptr;
+          rc = i8ie_malloc(ctx, (size_t)m * L->n * ph * pw, (void**)&tmp2);
+          if (rc == I8IE_OK) rc = i8ie_maxpool2d_u8(ctx, tmp, tmp2, m, L->n, cg.oh, cg.ow, pool_k, pool_s);
+          if (rc == I8IE_OK) rc = i8ie_launch_nchw_to_nhwc(ctx, tmp2, out, m, L->n, ph, pw, out_border);
+          i8ie_free(ctx, tmp2);
+        }
+      }
+      i8ie_free(ctx, tmp);
+      return rc;
+    }
+  }
+  const int ph = pool ? (cg.oh - pool_k) / pool_s + 1 : cg.oh, pw = pool ? (cg.ow - pool_k) / pool_s + 1 : cg.ow;
   const size_t in_bytes = (size_t)m * cg.c * cg.h * cg.w;
-  const size_t out_bytes = (size_t)m * cg.kc * cg.oh * cg.ow;
+  const size_t out_bytes = (size_t)m * cg.kc * ph * pw;
   const int path = force_fallback(ctx) ? PATH_F : L->path;
 
   if (path == PATH_F) {
@@ -662,6 +724,29 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
     const int Wg = (cg.ow - 1) * (cg.stride / 4) + L->kwg;
     const size_t t_bytes = in_layout == I8IE_LAYOUT_NHWC ? i8ie_align_up(in_bytes, 256) : 0;
     const size_t r_bytes = i8ie_align_up((size_t)m * Hp * Wg * 16, 256);
+    if (stem_takes(L, cg, pool ? pool_k : 0, pool_s) && (acc == nullptr || aligned16(acc))) {
+      // first-stage kernel (i8ie_stem.hip): space-to-depth image, conv (+ relu) (+ max-pool) in one contraction launch
+      const size_t s_bytes = i8ie_align_up(i8ie_stem_scratch_bytes(m, cg.kh, cg.kw, cg.stride, cg.oh, cg.ow), 256);
+      I8IE_TRY(i8ie_ws_reserve(ctx, t_bytes + s_bytes + o_bytes + 256));
+      uint8_t* ws = (uint8_t*)ctx->ws;
+      const uint8_t* src = in;
+      if (t_bytes) {
+        I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, in, ws, m, cg.c, cg.h, cg.w, in_border));
+        src = ws;
+      }
+      uint8_t* dst = o_bytes ? ws + t_bytes + s_bytes : out;
+      I8ieStemCall f{};
+      f.x = nullptr; f.xu8 = src; f.scratch = ws + t_bytes;
+      f.n = m; f.c = cg.c; f.h = cg.h; f.w = cg.w; f.q_scale = s_in; f.q_zp = zp_in;
+      f.KH = cg.kh; f.KW = cg.kw; f.stride = cg.stride; f.pad = cg.pad; f.OH = cg.oh; f.OW = cg.ow;
+      f.B = L->Bstem; f.Kpad = L->KpadStem; f.N = L->n; f.ocp = L->ocp;
+      f.s_in = s_in; f.s_w = L->s_w; f.s_out = L->s_out; f.zp_out = L->zp_out; f.relu = relu;
+      f.pool_k = pool ? pool_k : 0; f.pool_s = pool_s;
+      f.out = dst; f.ob = o_bytes ? 0 : out_border; f.out_s8 = 0; f.acc = acc;
+      I8IE_TRY(i8ie_stem_launch(ctx, f));
+      if (o_bytes) I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, dst, out, m, cg.kc, ph, pw, 0));
+      return I8IE_OK;
+    }
     I8IE_TRY(i8ie_ws_reserve(ctx, t_bytes + r_bytes + o_bytes + 256));
     uint8_t* ws = (uint8_t*)ctx->ws;
     const uint8_t* src = in;
@@ -705,18 +790,29 @@ int i8ie_layer_accepts_f32_input(const i8ie_layer* L, int h, int w, int* yes) {
   if (!L->conv || L->path != PATH_B || force_fallback(L->ctx)) return I8IE_OK;
   ConvGeom cg;
   if (conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg) != I8IE_OK) return I8IE_OK;
-  *yes = i8ie_first_supported(L->c, L->stride, L->n, L->K2, L->kh, L->kwg, cg.ow);
+  *yes = (stem_takes(L, cg, 0, 0) || i8ie_first_supported(L->c, L->stride, L->n, L->K2, L->kh, L->kwg, cg.ow)) ? 1 : 0;
   return I8IE_OK;
 }
 
-int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, int w, float q_scale, uint8_t q_zp,
-                                 int relu, uint8_t* out, int out_border, int32_t* acc) {
+int i8ie_layer_fuses_pool(const i8ie_layer* L, int h, int w, int pool_k, int pool_s, int* yes) {
+  I8IE_REQUIRE(L && yes, "null argument");
+  *yes = 0;
+  if (!L->conv || pool_k < 1 || pool_s < 1) return I8IE_OK;
+  ConvGeom cg;
+  if (conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg) != I8IE_OK) return I8IE_OK;
+  if (pool_k > cg.oh || pool_k > cg.ow) return I8IE_OK;
+  *yes = stem_takes(L, cg, pool_k, pool_s) ? 1 : 0;
+  return I8IE_OK;
+}
+
+int i8ie_layer_forward_f32_input_pool(i8ie_layer* L, const float* in, int m, int h, int w, float q_scale, uint8_t q_zp,
+                                      int relu, int pool_k, int pool_s, uint8_t* out, int out_border, int32_t* acc) {
   I8IE_REQUIRE(L && in && out, "null argument");
   I8IE_REQUIRE(m > 0 && out_border >= 0, "bad argument");
   int yes = 0;
   I8IE_TRY(i8ie_layer_accepts_f32_input(L, h, w, &yes));
   if (!yes) {
-    i8ie_set_error("i8ie_layer_forward_f32_input: layer/geometry not supported by the fused first-layer kernel");
+    i8ie_set_error("i8ie_layer_forward_f32_input: layer/geometry not supported by the fused first-layer kernels");
     return I8IE_ERR_STATE;
   }
   i8ie_ctx* ctx = L->ctx;
@@ -726,6 +822,31 @@ int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, i
   I8IE_TRY(ensure_offsets(L, q_scale, q_zp));
   ConvGeom cg;
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
+  const bool pool = pool_k > 1 || (pool_k == 1 && pool_s > 1);
+  if (pool) {
+    I8IE_REQUIRE(pool_s > 0 && pool_k <= cg.oh && pool_k <= cg.ow, "max-pool window larger than the convolution's output");
+  }
+  if (stem_takes(L, cg, pool ? pool_k : 0, pool_s)) {
+    I8IE_TRY(i8ie_ws_reserve(ctx, i8ie_stem_scratch_bytes(m, cg.kh, cg.kw, cg.stride, cg.oh, cg.ow) + 256));
+    I8ieStemCall f{};
+    f.x = in; f.xu8 = nullptr; f.scratch = (uint8_t*)ctx->ws;
+    f.n = m; f.c = cg.c; f.h = h; f.w = w; f.q_scale = q_scale; f.q_zp = q_zp;
+    f.KH = cg.kh; f.KW = cg.kw; f.stride = cg.stride; f.pad = cg.pad; f.OH = cg.oh; f.OW = cg.ow;
+    f.B = L->Bstem; f.Kpad = L->KpadStem; f.N = L->n; f.ocp = L->ocp;
+    f.s_in = q_scale; f.s_w = L->s_w; f.s_out = L->s_out; f.zp_out = L->zp_out; f.relu = relu;
+    f.pool_k = pool ? pool_k : 0; f.pool_s = pool_s;
+    f.out = out; f.ob = out_border; f.out_s8 = 0; f.acc = acc;
+    return i8ie_stem_launch(ctx, f);
+  }
+  if (pool) {  // the older first-layer kernel does not pool: conv (+ relu) into a temporary, then max_pool2d<u8> on NHWC
+    I8IE_REQUIRE(L->n % 16 == 0, "i8ie_layer_forward_f32_input_pool: out features % 16 != 0");
+    uint8_t* tmp = nullptr;
+    I8IE_TRY(i8ie_malloc(ctx, (size_t)m * L->n * cg.oh * cg.ow, (void**)&tmp));
+    int rc = i8ie_layer_forward_f32_input_pool(L, in, m, h, w, q_scale, q_zp, relu, 0, 0, tmp, 0, acc);
+    if (rc == I8IE_OK) rc = i8ie_launch_maxpool_nhwc(ctx, tmp, 0, out, out_border, m, L->n, cg.oh, cg.ow, pool_k, pool_s, 0);
+    i8ie_free(ctx, tmp);
+    return rc;
+  }
   I8IE_TRY(i8ie_ws_reserve(ctx, i8ie_first_scratch_bytes(m, cg.kh, L->kwg, cg.stride, cg.oh, cg.ow) + 256));
   I8ieFirstCall c{};
   c.x = in; c.grouped = nullptr; c.scratch = (uint8_t*)ctx->ws;
@@ -735,6 +856,11 @@ int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, i
   c.s_in = q_scale; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
   c.out = out; c.ob = out_border; c.acc = acc;
   return i8ie_first_launch(ctx, c);
+}
+
+int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, int w, float q_scale, uint8_t q_zp,
+                                 int relu, uint8_t* out, int out_border, int32_t* acc) {
+  return i8ie_layer_forward_f32_input_pool(L, in, m, h, w, q_scale, q_zp, relu, 0, 0, out, out_border, acc);
 }
 
 int i8ie_layer_forward(i8ie_layer* L, const uint8_t* in, int m, int h, int w, float s_in, uint8_t zp_in, uint8_t* out,
@@ -749,6 +875,7 @@ int i8ie_layer_destroy(i8ie_layer* L) {
   i8ie_free(ctx, L->qb);
   i8ie_free(ctx, L->Bpack);
   i8ie_free(ctx, L->Bpack2);
+  if (L->Bstem) i8ie_free(ctx, L->Bstem);
   for (const I8ieWCache::Ent& e : L->wc.ents) i8ie_free(ctx, e.buf);
   i8ie_free(ctx, L->wsum);
   i8ie_free(ctx, L->oc);

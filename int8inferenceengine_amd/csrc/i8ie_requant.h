@@ -61,6 +61,29 @@ __device__ __forceinline__ uint32_t i8ie_requant_pack4(const int (&c)[4], const 
   return packed;
 }
 
+// The same in two halves, for epilogues that keep several independent packs in flight without a branch between them:
+// the estimate (+ how far the closest value is from a rounding boundary), and the exact replay for a pack whose
+// `worst` came out below 2^-13 (or whose scales do not allow the estimate: worst = 0 then).
+__device__ __forceinline__ uint32_t i8ie_requant_est4(const int (&c)[4], const I8ieRequant& q, float lof, float& worst) {
+  uint32_t packed = 0;
+  float w = q.fast ? 1.0f : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float e = __builtin_fmaf((float)c[r], q.ms, q.zpf - 0.5f);
+    packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaxf(e, lof), r, packed);
+    w = __builtin_fminf(w, __builtin_fabsf(__builtin_amdgcn_fractf(e) - 0.5f));
+  }
+  worst = w;
+  return packed;
+}
+__device__ __forceinline__ bool i8ie_requant_est_ok(float worst) { return worst >= 1.220703125e-4f; }
+__device__ __forceinline__ uint32_t i8ie_requant_exact4(const int (&c)[4], const I8ieRequant& q, int lo) {
+  uint32_t packed = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) packed |= (uint32_t)i8ie_requant_exact((float)c[r], q, lo) << (8 * r);
+  return packed;
+}
+
 #if defined(I8IE_DIAG)
 // (Measured and dropped: the same estimate two values at a time with v_pk_fma_f32 / v_pk_add_f32 / v_min3_f32,
 // 5.5 instead of 7 instructions per value, made the conv2-5 kernels 8-12 % SLOWER on MI355X: the packed fp32

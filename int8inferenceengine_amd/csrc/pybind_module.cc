@@ -280,6 +280,10 @@ std::shared_ptr<Storage> nhwc_storage(const std::vector<ssize_t>& shp, int b, in
 // and its upstream chain (whose nodes cache in the same way) is never launched again.
 struct PendNode {
   std::function<std::shared_ptr<Storage>(bool, int)> fn;
+  // a conv layer whose kernel can fold a following max_pool2d into its epilogue (i8ie_layer_fuses_pool): arguments
+  // relu, border of the POOLED result, pool kernel_size, stride; returns null when this launch cannot (the caller
+  // then pools the unfused result)
+  std::function<std::shared_ptr<Storage>(bool, int, int, int)> fn_pool;
   struct Made {
     bool relu;
     int border;
@@ -660,6 +664,14 @@ Tensor<u8_t> max_pool2d_u8(Tensor<u8_t>& in, ssize_t k, ssize_t s) {  // src/fun
   // deferred so that a consuming conv can ask for a zero-point border around the result
   out.pend = make_pend(
       [src, ishp, oshp, zp, kk, ss](bool relu, int border) mutable {
+        if (src.pend && src.pend->fn_pool && src.pend.use_count() == 1 && src.pend->made.empty()) {
+          // relu(layer(x)) still pending, nobody else holds it (no second consumer, not observable any more), and its
+          // kernel pools in the epilogue: one launch, no unpooled tensor.  With another holder the layer launches once,
+          // unfused, and every consumer reads that result (a recorded launch never runs twice).
+          // (a relu behind the pool folds in as well: max-pool and relu commute, both are monotone)
+          std::shared_ptr<Storage> st = src.pend->fn_pool(src.pend_relu || relu, border, kk, ss);
+          if (st) return st;
+        }
         const uint8_t* ip = src.dptr_any();
         std::shared_ptr<Storage> st;
         const size_t logical = (size_t)oshp[0] * oshp[1] * oshp[2] * oshp[3];
@@ -953,6 +965,34 @@ class BaseLayer {
           // launch in `x = relu(layer(x))`, later if the un-fused result is observed as well)
           return st;
         });
+    if (spatial) {
+      Tensor<u8_t> srcp = in;
+      out.pend->fn_pool = [handle, srcp, s_in, zp_in, zp_out, m, h, w, oshp](bool relu, int border, int pk, int ps) mutable
+          -> std::shared_ptr<Storage> {
+        int yes = 0, out_layout = I8IE_LAYOUT_NCHW, pad = 0;
+        check(i8ie_layer_fuses_pool(handle.get(), h, w, pk, ps, &yes));
+        check(i8ie_layer_preferred_layout(handle.get(), &out_layout));
+        if (!yes || out_layout != I8IE_LAYOUT_NHWC) return nullptr;
+        check(i8ie_layer_padding(handle.get(), &pad));
+        const std::vector<ssize_t> pshp = {oshp[0], oshp[1], (oshp[2] - pk) / ps + 1, (oshp[3] - pk) / ps + 1};
+        if (srcp.pend && srcp.qsrc && !srcp.pend_relu) {
+          int f32ok = 0;
+          check(i8ie_layer_accepts_f32_input(handle.get(), h, w, &f32ok));
+          if (f32ok) {  // quantize + conv + relu + max-pool in one contraction launch, reading the FP32 input
+            auto st = nhwc_storage(pshp, border, zp_out);
+            check(i8ie_layer_forward_f32_input_pool(handle.get(), (const float*)srcp.qsrc->device_ptr(), m, h, w, srcp.qscale,
+                                                    srcp.qzp, relu ? 1 : 0, pk, ps, (uint8_t*)st->dev, border, nullptr));
+            return st;
+          }
+        }
+        srcp.realize(pad);
+        const uint8_t* ip = srcp.dptr_any();
+        auto st = nhwc_storage(pshp, border, zp_out);
+        check(i8ie_layer_forward_pool(handle.get(), ip, srcp.st->layout, srcp.st->border, m, h, w, s_in, zp_in, relu ? 1 : 0,
+                                      pk, ps, (uint8_t*)st->dev, I8IE_LAYOUT_NHWC, border, nullptr));
+        return st;
+      };
+    }
     if (!spatial && out.shape.size() == 2 && out.shape[1] <= 16) {
       // dequantize(layer(x)) of a classifier head: one fused launch (i8ie_layer_forward_dequant)
       Tensor<u8_t> src2 = in;

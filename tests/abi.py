@@ -320,3 +320,53 @@ class Ctx:
             if bb is not None:
                 bb.free()
         return r
+
+    def layer_forward_pool(self, q_in_nchw, qw, qb, s_in, zp_in, s_w, s_out, zp_out, stride=1, pad=0, in_nhwc=False,
+                           out_nhwc=False, relu=False, in_border=0, out_border=0, pool=None, variant=0):
+        """i8ie_layer_forward_pool (pool=(k, s)) or i8ie_layer_forward_fused (pool=None) of a conv layer.
+        Returns (out NCHW, acc [n, oh*ow, kc])."""
+        q_in = np.ascontiguousarray(q_in_nchw, np.uint8)
+        qw = np.ascontiguousarray(qw, np.int8)
+        qb = np.ascontiguousarray(qb, np.int8)
+        m, c, h, w = q_in.shape
+        kc, _, kh, kw = qw.shape
+        oh, ow = (h - kh + 2 * pad) // stride + 1, (w - kw + 2 * pad) // stride + 1
+        ph, pw = (oh, ow) if pool is None else ((oh - pool[0]) // pool[1] + 1, (ow - pool[0]) // pool[1] + 1)
+        L = C.c_void_p()
+        ck(lib().i8ie_conv2d_create(self.h, qw.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p), kc, c, kh, kw,
+                                    stride, pad, C.c_float(s_w), C.byref(L)))
+        ck(lib().i8ie_layer_set_output_qparams(L, C.c_float(s_out), C.c_uint8(zp_out)))
+        phys_in = self.to_phys(q_in, in_border, zp_in) if in_nhwc else q_in
+        di = self.put(phys_in)
+        oshape = (m, ph + 2 * out_border, pw + 2 * out_border, kc) if out_nhwc else (m, kc, ph, pw)
+        out = self.empty(oshape, np.uint8)
+        acc = self.empty((m, oh * ow, kc), np.int32)
+        if out_nhwc and out_border:
+            ck(lib().i8ie_fill_border_u8(self.h, out.ptr, m, kc, ph, pw, out_border, C.c_uint8(zp_out)))
+        ck(lib().i8ie_ctx_set_option(self.h, 2, variant))
+        try:
+            if pool is None:
+                ck(lib().i8ie_layer_forward_fused(L, di.ptr, 1 if in_nhwc else 0, in_border, m, h, w, C.c_float(s_in),
+                                                  C.c_uint8(zp_in), 1 if relu else 0, out.ptr, 1 if out_nhwc else 0,
+                                                  out_border, acc.ptr))
+            else:
+                ck(lib().i8ie_layer_forward_pool(L, di.ptr, 1 if in_nhwc else 0, in_border, m, h, w, C.c_float(s_in),
+                                                 C.c_uint8(zp_in), 1 if relu else 0, pool[0], pool[1], out.ptr,
+                                                 1 if out_nhwc else 0, out_border, acc.ptr))
+        finally:
+            ck(lib().i8ie_ctx_set_option(self.h, 2, 0))
+        phys = out.get()
+        o = phys
+        if out_nhwc:
+            b = out_border
+            if b:
+                ring = phys.copy()
+                ring[:, b:-b, b:-b, :] = zp_out
+                assert (ring == zp_out).all(), "output border must hold zp_out"
+                o = phys[:, b:-b, b:-b, :]
+            o = np.ascontiguousarray(o.transpose(0, 3, 1, 2))
+        r = (o, acc.get())
+        lib().i8ie_layer_destroy(L)
+        for bb in (di, out, acc):
+            bb.free()
+        return r

@@ -247,9 +247,18 @@ def test_recorded_launches_are_shared_between_holders(i8ie):
         again = i8ie.max_pool2d(y, 3, 2).numpy()
     finally:
         prof = cx.profile_stop()
-    convs = sum(v[0] for k, v in prof.items() if k.startswith("conv_smallc") or k.startswith("igemm_conv") or k.startswith("pp_conv"))
+    convs = sum(v[0] for k, v in prof.items() if k.startswith(("stem_conv", "conv_smallc", "igemm_conv")))
     assert convs == 1, prof
     assert np.array_equal(a, again) and a.shape == (2, 96, 27, 27) and b.shape == (2, 96, 27, 27) and yv.shape == (2, 96, 55, 55)
+    # ... while the same expression with no other holder of the conv output is ONE contraction launch with the pool
+    # folded into it (csrc/i8ie_stem.hip), and the same bytes
+    cx.profile_start()
+    try:
+        fused = i8ie.max_pool2d(i8ie.relu(net.conv1(q)), 3, 2).numpy()
+    finally:
+        prof2 = cx.profile_stop()
+    assert prof2.get("stem_conv_pool", (0,))[0] == 1 and "maxpool_u8_nhwc" not in prof2, prof2
+    assert np.array_equal(fused, a)
     # the values are the reference's: pools of the observed tensor
     want = np.zeros_like(a)
     for m in range(3):

@@ -1,5 +1,7 @@
-"""Fused first layer (quantize + small-C strided conv, FP32 NCHW in, NHWC u8 out) through the
-C-ABI entry i8ie_layer_forward_f32_input, against oracle quantize -> conv2d (-> relu)."""
+"""Fused first stage (quantize + small-C strided conv (+ relu) (+ max-pool), FP32 NCHW in, NHWC u8 out) through the
+C-ABI entries i8ie_layer_forward_f32_input(_pool) and, from u8 input, i8ie_layer_forward_pool, against the oracle's
+quantize -> conv2d (-> relu) (-> max_pool2d): u8 outputs and the convolution's INT32 accumulators.  The profile
+hooks confirm which kernel ran (csrc/i8ie_stem.hip where it takes the geometry, csrc/i8ie_first.hip otherwise)."""
 import ctypes as C
 
 import numpy as np
@@ -18,11 +20,17 @@ def gpu():
     c.close()
 
 
-def run_first(gpu, x, qw, qb, stride, pad, q_scale, q_zp, s_w, s_out, zp_out, relu, ob):
+class _Entry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_uint64), ("total_ms", C.c_double),
+                ("total_ops", C.c_double), ("total_bytes", C.c_double)]
+
+
+def run_first(gpu, x, qw, qb, stride, pad, q_scale, q_zp, s_w, s_out, zp_out, relu, ob, pool=None, names=None):
     lib = abi.lib()
     n, c, h, w = x.shape
     kc, _, kh, kw = qw.shape
     oh, ow = (h - kh + 2 * pad) // stride + 1, (w - kw + 2 * pad) // stride + 1
+    ph, pw = (oh, ow) if pool is None else ((oh - pool[0]) // pool[1] + 1, (ow - pool[0]) // pool[1] + 1)
     L = C.c_void_p()
     abi.ck(lib.i8ie_conv2d_create(gpu.h, qw.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p), kc, c, kh, kw,
                                   stride, pad, C.c_float(s_w), C.byref(L)))
@@ -33,11 +41,23 @@ def run_first(gpu, x, qw, qb, stride, pad, q_scale, q_zp, s_w, s_out, zp_out, re
         lib.i8ie_layer_destroy(L)
         return None
     dx = gpu.put(np.ascontiguousarray(x, np.float32))
-    out = gpu.empty((n, oh + 2 * ob, ow + 2 * ob, kc), np.uint8)
+    out = gpu.empty((n, ph + 2 * ob, pw + 2 * ob, kc), np.uint8)
     acc = gpu.empty((n, oh * ow, kc), np.int32)
-    abi.ck(lib.i8ie_fill_border_u8(gpu.h, out.ptr, n, kc, oh, ow, ob, C.c_uint8(zp_out)))
-    abi.ck(lib.i8ie_layer_forward_f32_input(L, dx.ptr, n, h, w, C.c_float(q_scale), C.c_uint8(q_zp), 1 if relu else 0,
-                                            out.ptr, ob, acc.ptr))
+    abi.ck(lib.i8ie_fill_border_u8(gpu.h, out.ptr, n, kc, ph, pw, ob, C.c_uint8(zp_out)))
+    abi.ck(lib.i8ie_profile_start(gpu.h, 0))
+    try:
+        if pool is None:
+            abi.ck(lib.i8ie_layer_forward_f32_input(L, dx.ptr, n, h, w, C.c_float(q_scale), C.c_uint8(q_zp),
+                                                    1 if relu else 0, out.ptr, ob, acc.ptr))
+        else:
+            abi.ck(lib.i8ie_layer_forward_f32_input_pool(L, dx.ptr, n, h, w, C.c_float(q_scale), C.c_uint8(q_zp),
+                                                         1 if relu else 0, pool[0], pool[1], out.ptr, ob, acc.ptr))
+    finally:
+        ents = (_Entry * 64)()
+        cnt = C.c_int(0)
+        abi.ck(lib.i8ie_profile_stop(gpu.h, ents, 64, C.byref(cnt)))
+        if names is not None:
+            names.extend(ents[i].name.decode().split("|")[0] for i in range(cnt.value))
     phys = out.get()
     acc_h = acc.get()
     lib.i8ie_layer_destroy(L)
@@ -55,12 +75,15 @@ def run_first(gpu, x, qw, qb, stride, pad, q_scale, q_zp, s_w, s_out, zp_out, re
 GEOMS = [
     # n, c, h, w, kc, k, stride, pad
     (2, 3, 224, 224, 96, 11, 4, 2),   # AlexNet conv1
-    (5, 3, 224, 224, 96, 11, 4, 2),   # more bands than one block walks at once
-    (3, 3, 67, 83, 64, 7, 4, 3),      # non-square, ragged last band
-    (4, 1, 40, 40, 32, 5, 4, 0),      # one channel, no padding
-    (2, 2, 50, 31, 96, 3, 8, 1),      # stride 8, two channels
-    (3, 3, 35, 35, 160, 11, 4, 5),    # 5 feature tiles, big padding
+    (5, 3, 224, 224, 96, 11, 4, 2),
+    (3, 3, 67, 83, 64, 7, 4, 3),      # non-square; 21-pixel rows: strips of 6 rows; two feature groups, K = 192
+    (4, 1, 40, 40, 32, 5, 4, 0),      # one channel, no padding, one feature group
+    (2, 2, 50, 31, 96, 3, 8, 1),      # stride 8, two channels, K = 48 (two k-steps)
+    (3, 3, 35, 35, 160, 11, 4, 5),    # 5 feature tiles: beyond the first-stage kernel, the older kernel takes it
+    (600, 3, 43, 43, 64, 7, 4, 3),    # more images than CUs: blocks walk two or three images (ring and patch sequence
+                                      # run through the image boundary)
 ]
+POOLS = [None, (3, 2), (2, 2)]
 
 
 @pytest.mark.parametrize("variant", [0])
@@ -77,13 +100,38 @@ def test_fused_first_layer_bit_exact(gpu, orc, geom, variant):
     want, want_acc = orc.conv2d(q_in, cs["qw"], cs["qb"], stride, pad, q_scale, q_zp, cs["s_w"], cs["s_out"], cs["zp_out"],
                                 want_acc=True)
     for relu, ob in ((False, 0), (True, 2)):
-        got = run_first(gpu, x, cs["qw"], cs["qb"], stride, pad, q_scale, q_zp, cs["s_w"], cs["s_out"], cs["zp_out"],
-                        relu, ob)
-        assert got is not None, "geometry should be supported"
-        got, acc = got
-        assert np.array_equal(acc, want_acc)  # INT32 pre-requant accumulators of the first-layer kernel itself
-        assert np.array_equal(got, orc.relu(want, cs["zp_out"]) if relu else want)
+        for pool in POOLS:
+            names = []
+            got = run_first(gpu, x, cs["qw"], cs["qb"], stride, pad, q_scale, q_zp, cs["s_w"], cs["s_out"], cs["zp_out"],
+                            relu, ob, pool, names)
+            assert got is not None, "geometry should be supported"
+            got, acc = got
+            if kc <= 96:  # the kernel under test is the one that ran, with the pool inside it
+                assert ("stem_conv_pool" if pool else "stem_conv") in names and "maxpool_u8_nhwc" not in names, names
+            assert np.array_equal(acc, want_acc)  # INT32 pre-requant accumulators of the first-stage kernel itself
+            ref = orc.relu(want, cs["zp_out"]) if relu else want
+            if pool:
+                ref = orc.max_pool2d(ref, pool[0], pool[1])
+            assert np.array_equal(got, ref), (relu, ob, pool)
     abi.ck(abi.lib().i8ie_ctx_set_option(gpu.h, 2, 0))
+
+
+@pytest.mark.parametrize("geom", GEOMS[:5])
+def test_first_stage_from_u8_input(gpu, orc, geom):
+    """The same kernels fed by an already quantised u8 tensor (NCHW, or NHWC as the engine keeps it between layers)
+    through i8ie_layer_forward_pool / i8ie_layer_forward_fused, incl. an NCHW result and non-default input qparams."""
+    n, c, h, w, kc, k, stride, pad = geom
+    cs = synth.conv_case(orc, 17 + sum(geom), n, c, h, w, kc, k, stride, pad, s_in=0.031, zp_in=99)
+    for in_nhwc, out_nhwc, relu, ob, pool in ((False, True, True, 1, (3, 2)), (True, True, False, 0, None),
+                                              (False, False, True, 0, (2, 2))):
+        out, acc = gpu.layer_forward_pool(cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"], cs["s_out"],
+                                          cs["zp_out"], stride=stride, pad=pad, in_nhwc=in_nhwc, out_nhwc=out_nhwc,
+                                          relu=relu, out_border=ob, pool=pool)
+        ref = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
+        if pool:
+            ref = orc.max_pool2d(ref, pool[0], pool[1])
+        assert np.array_equal(acc, cs["acc"])
+        assert np.array_equal(out, ref), (in_nhwc, out_nhwc, relu, ob, pool)
 
 
 def test_unsupported_geometries_say_no(gpu, orc):
