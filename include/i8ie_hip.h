@@ -79,6 +79,12 @@ int i8ie_ctx_set_option(i8ie_ctx* ctx, int option, int value);
  * layers (the reference's own GEMM output is HWC before its transpose, src/conv2d.cc:134-136). */
 #define I8IE_LAYOUT_NCHW 0
 #define I8IE_LAYOUT_NHWC 1
+/* NHWC with every byte stored as value ^ 0x80 (= value - 128 as s8; border bytes: zero point ^ 0x80).  The matrix
+ * cores have no unsigned 8-bit operand: a conv kernel re-biases its activations on the way in (the exact term
+ * 128 * sum_k q_w[j,k] joins oc[j]).  Between two conv layers of this library the producer can store that form
+ * directly and the consumer skip its re-bias pass.  Accepted as in_layout / out_layout of the conv layer forwards;
+ * i8ie_rebias_u8 converts a whole buffer either way. */
+#define I8IE_LAYOUT_NHWC_S8 2
 
 /* ---- per-kernel timing (measurement aid; nothing like it in the reference) ---
  * Between start and stop every kernel launch of this ctx is bracketed by HIP
@@ -163,6 +169,8 @@ int i8ie_quantize_f32_u8(i8ie_ctx* ctx, const float* in_dev, uint8_t* out_dev, i
 /* dequantize(Tensor<u8>&)  src/quantize_utils.cc:38-42,54-58, src/pybind11.cc:46-48 */
 int i8ie_dequantize_u8_f32(i8ie_ctx* ctx, const uint8_t* in_dev, float* out_dev, int64_t n,
                            float scale, uint8_t zero_point);
+/* out = in ^ 0x80 over n bytes (in place allowed): plain u8 <-> the re-biased bytes of I8IE_LAYOUT_NHWC_S8 */
+int i8ie_rebias_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int64_t n);
 /* relu<u8_t>  src/functional.cc:15-26:  out = in > zp ? in : zp */
 int i8ie_relu_u8(i8ie_ctx* ctx, const uint8_t* in_dev, uint8_t* out_dev, int64_t n,
                  uint8_t zero_point);
@@ -289,10 +297,16 @@ int i8ie_layer_preferred_layout(const i8ie_layer* layer, int* layout);
  * pooling afterwards), no unpooled tensor is ever written; otherwise the call runs the convolution into a
  * temporary and the max-pool kernel behind it.  Identical bytes to i8ie_layer_forward_fused followed by
  * i8ie_maxpool2d_u8(_nhwc) either way.  acc_dbg_dev: the convolution's (unpooled) accumulators [m, oh*ow, kc]. */
-int i8ie_layer_fuses_pool(const i8ie_layer* layer, int h, int w, int kernel_size, int stride, int* yes);
+int i8ie_layer_fuses_pool(const i8ie_layer* layer, int m, int h, int w, int kernel_size, int stride, int* yes);
 int i8ie_layer_forward_pool(i8ie_layer* layer, const uint8_t* in_dev, int in_layout, int in_border, int m, int h, int w,
                             float s_in, uint8_t zp_in, int relu, int kernel_size, int stride, uint8_t* out_dev,
                             int out_layout, int out_border, int32_t* acc_dbg_dev);
+/* I8IE_LAYOUT_NHWC_S8 between two conv layers: *reads = 1 when this layer's kernel (at batch m, input h x w, with this
+ * pool folded in; kernel_size <= 1: none) consumes re-biased input as it is, *stores = 1 when it can store its result
+ * re-biased.  The forward calls accept the layout either way (they convert around a kernel that does not); a caller
+ * that owns both ends asks here first, so that no conversion launch is ever needed. */
+int i8ie_layer_rebiased_io(const i8ie_layer* layer, int m, int h, int w, int kernel_size, int stride, int* reads,
+                           int* stores);
 /* First layer fused with the input quantisation (Module.__call__ quantises the FP32 input with
  * 0.025 / 127, i8ie/module.py:20, and hands it straight to the first Conv2d): reads FP32 NCHW,
  * computes q = (u8)(x / q_scale + q_zp) exactly as src/quantize_utils.cc:44-52 and the conv of
@@ -308,7 +322,7 @@ int i8ie_layer_forward_f32_input(i8ie_layer* layer, const float* in_nchw_dev, in
  * quantize -> conv1 -> relu -> max-pool of AlexNet in one contraction launch (csrc/i8ie_stem.hip) */
 int i8ie_layer_forward_f32_input_pool(i8ie_layer* layer, const float* in_nchw_dev, int m, int h, int w, float q_scale,
                                       uint8_t q_zp, int relu, int kernel_size, int stride, uint8_t* out_nhwc_dev,
-                                      int out_border, int32_t* acc_dbg_dev);
+                                      int out_layout /* NHWC or NHWC_S8 */, int out_border, int32_t* acc_dbg_dev);
 /* padding of a conv layer (0 for Linear): the input border that makes its gather predicate-free */
 int i8ie_layer_padding(const i8ie_layer* layer, int* pad);
 int i8ie_layer_destroy(i8ie_layer* layer);

@@ -44,8 +44,12 @@ struct I8ieIgemmCall {
   int ksplit;        // amode 0 only: > 1 = split K over that many slices (partial must hold ksplit*M*N int32)
   int32_t* partial;
   I8ieWCache* wcache;  // amode 1: the layer handle's cache of weights re-packed by i8ie_pconv.hip / i8ie_tconv.hip; may be null
+  // amode 1, honoured by i8ie_pconv.hip only (ask i8ie_pconv_takes first; the tiled kernel ignores them):
+  int pool_k, pool_s;  // max_pool2d behind the (relu'd) convolution: `out` is then the pooled tensor, ob its border
+  int a_s8, out_s8;    // input bytes / output bytes stored re-biased (^0x80: I8IE_LAYOUT_NHWC_S8)
 };
 int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
+size_t i8ie_igemm_chunk_limit();  // activations at or beyond this many bytes run as several launches
 
 #if defined(I8IE_DIAG)
 // tools/diag/csrc/i8ie_pp.hip (diagnostic build only): the persistent ping-pong form of the amode-1 contraction.
@@ -56,6 +60,7 @@ int i8ie_pp_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 // streamed in fragment order).  Returns 1 when it took the launch, 0 when the shape is not its (the caller then
 // runs the tiled kernel), < 0 on error.
 int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
+int i8ie_pconv_takes(i8ie_ctx* ctx, const I8ieIgemmCall& c);  // dry run of the same decision: 1 / 0
 
 // i8ie_tconv.hip: the patch-stationary contraction with two wave teams half a tile apart (epilogues, patch waits
 // and re-bias passes of one team under the MFMAs of the other).  Same return convention.

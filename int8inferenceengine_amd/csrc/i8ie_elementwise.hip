@@ -98,6 +98,19 @@ __global__ __launch_bounds__(kThreads) void relu_u8_kernel(const uint8_t* in,  /
   }
 }
 
+// x ^ 0x80 over a buffer: u8 <-> the re-biased form (value - 128 as s8) of I8IE_LAYOUT_NHWC_S8; may run in place
+__global__ __launch_bounds__(kThreads) void rebias_u8_kernel(const uint8_t* in, uint8_t* out, int64_t n) {
+  const int64_t nvec = n >> 4;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += stride) {
+    uint4 x = reinterpret_cast<const uint4*>(in)[v];
+    x.x ^= 0x80808080u; x.y ^= 0x80808080u; x.z ^= 0x80808080u; x.w ^= 0x80808080u;
+    reinterpret_cast<uint4*>(out)[v] = x;
+  }
+  const int64_t t0 = nvec << 4;
+  if (blockIdx.x == 0 && threadIdx.x < (n - t0)) out[t0 + threadIdx.x] = in[t0 + threadIdx.x] ^ 0x80;
+}
+
 // ---- a8: src/functional.cc:36-64 (NCHW, floor, no padding, running max from 0)
 __global__ __launch_bounds__(kThreads) void maxpool_u8_nchw_kernel(const uint8_t* __restrict__ in,
                                                                    uint8_t* __restrict__ out,
@@ -235,6 +248,18 @@ int i8ie_relu_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int64_t n, uint
   I8ieProfScope prof(ctx, "relu_u8", 0.0, 2.0 * n);
   relu_u8_kernel<<<grid_for((n >> 4) + 1), kThreads, 0, ctx->stream>>>(in, out, n,
                                                                         z | (z << 8) | (z << 16) | (z << 24));
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
+}
+
+int i8ie_rebias_u8(i8ie_ctx* ctx, const uint8_t* in, uint8_t* out, int64_t n) {
+  I8IE_REQUIRE(ctx && in && out, "null argument");
+  I8IE_REQUIRE(n >= 0, "negative size");
+  I8IE_REQUIRE(aligned16(in) && aligned16(out), "buffers must be 16-byte aligned");
+  if (n == 0) return I8IE_OK;
+  I8IE_HIP_TRY(hipSetDevice(ctx->device));
+  I8ieProfScope prof(ctx, "rebias_u8", 0.0, 2.0 * n);
+  rebias_u8_kernel<<<grid_for((n >> 4) + 1), kThreads, 0, ctx->stream>>>(in, out, n);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }

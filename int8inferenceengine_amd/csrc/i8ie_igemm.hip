@@ -1039,6 +1039,14 @@ int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, doubl
     }
 #endif
   }
+#if defined(I8IE_DIAG)
+  if (AMODE == 0 && ctx->variant == 13 && a.ksplit <= 1)  // Linear, 128 x 128 tiles, two 64 KiB DMA stages, one block per CU
+    return launch_cfg<AMODE, 2, 2, 2, 2, BIAS, ACC, 7>(ctx, a, "igemm_lin_128x128_dma2", kbytes, ops, bytes);
+  if (AMODE == 0 && ctx->variant == 14 && a.ksplit <= 1)  // Linear, 128 x 128 tiles, one DMA stage
+    return launch_cfg<AMODE, 2, 2, 2, 2, BIAS, ACC, 5>(ctx, a, "igemm_lin_128x128_dma1", kbytes, ops, bytes);
+  if (AMODE == 0 && ctx->variant == 15 && a.ksplit <= 1)  // Linear, 128 x 128 tiles, register staging
+    return launch_cfg<AMODE, 2, 2, 2, 2, BIAS, ACC, 3>(ctx, a, "igemm_lin_128x128_reg", kbytes, ops, bytes);
+#endif
   // Linear (few, short split-K slices per block) measured 20 % slower with DMA staging: register staging there
   if (ctx->variant == 3 || (AMODE == 0 && ctx->variant != 5))
     return launch_tile_var<AMODE, BIAS, ACC, 3>(ctx, a, kbytes, ops, bytes);
@@ -1062,6 +1070,8 @@ static size_t igemm_chunk_limit() {
   return v;
 }
 
+size_t i8ie_igemm_chunk_limit() { return igemm_chunk_limit(); }
+
 int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   I8IE_REQUIRE(c.M > 0 && c.N > 0 && c.Kpad > 0 && c.Kpad % BK2 == 0, "igemm dimensions");
   I8IE_REQUIRE((reinterpret_cast<uintptr_t>(c.A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(c.B) & 15u) == 0,
@@ -1069,6 +1079,7 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   // (the kernel also keeps bordered-output pixel indices in 32 bits)
   const size_t out_pixels = c.amode == 1 ? (size_t)(c.M / (c.OH * c.OW)) * (c.OH + 2 * c.ob) * (c.OW + 2 * c.ob) : 0;
   if (c.a_bytes >= igemm_chunk_limit() || out_pixels >= ((size_t)1 << 32)) {
+    I8IE_REQUIRE(!(c.pool_k > 1 || c.a_s8 || c.out_s8), "igemm: pool / re-biased layout on a launch that needs chunking");
     const size_t limit = igemm_chunk_limit();
     const int P = c.amode == 1 ? c.OH * c.OW : 1;  // rows per unit (image / row)
     const size_t unit_in = c.amode == 1 ? (size_t)c.Hp * c.Wp * c.C : (size_t)c.lda;
@@ -1121,6 +1132,8 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     const int took = i8ie_pconv_try_launch(ctx, c);
     if (took != 0) return took < 0 ? took : I8IE_OK;
   }
+  // (the kernels below know neither the folded max-pool nor the re-biased layouts: callers ask i8ie_pconv_takes first)
+  I8IE_REQUIRE(!(c.amode == 1 && (c.pool_k > 1 || c.a_s8 || c.out_s8)), "igemm: pool / re-biased layout without the patch-stationary kernel");
   IgemmArgs a{};
   a.A = c.A;
   a.a_bytes = (unsigned)c.a_bytes;

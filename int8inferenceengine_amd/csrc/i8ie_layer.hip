@@ -504,18 +504,34 @@ static bool stem_takes(const i8ie_layer* L, const ConvGeom& cg, int pool_k, int 
          i8ie_stem_supported(cg.c, cg.stride, L->n, cg.kh, cg.kw, cg.oh, cg.ow, pool_k, pool_s) != 0;
 }
 
+// would the patch-stationary kernel (i8ie_pconv.hip) take this conv launch, with this pool folded in and these
+// re-biased layouts?  (it answers from the geometry and the batch; nothing is launched)
+static bool pconv_probe(i8ie_layer* L, const ConvGeom& cg, int m, int in_border, int pool_k, int pool_s, bool a_s8, bool out_s8) {
+  if (!L->conv || L->path != PATH_A || force_fallback(L->ctx)) return false;
+  const int b = in_border > cg.pad ? in_border : cg.pad;
+  I8ieIgemmCall q{};
+  q.amode = 1; q.M = m * cg.oh * cg.ow; q.B = L->Bpack2; q.Kpad = L->Kpad2; q.Npad = L->Npad;
+  q.Kchunks = L->K2 / 16; q.N = L->n; q.wcache = &L->wc; q.OH = cg.oh; q.OW = cg.ow;
+  q.Hp = cg.h + 2 * b; q.Wp = cg.w + 2 * b; q.C = cg.c; q.KH = cg.kh; q.KW = cg.kw; q.sh = q.sw = cg.stride;
+  q.a_bytes = (size_t)m * q.Hp * q.Wp * cg.c;
+  q.pool_k = pool_k; q.pool_s = pool_s; q.a_s8 = a_s8 ? 1 : 0; q.out_s8 = out_s8 ? 1 : 0;
+  return q.a_bytes < i8ie_igemm_chunk_limit() && i8ie_pconv_takes(L->ctx, q) == 1;
+}
+
 static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, int in_border, int m, int h, int w,
                               float s_in, uint8_t zp_in, int relu, int pool_k, int pool_s, uint8_t* out, int out_layout,
                               int out_border, int32_t* acc, float* out_f32) {
   I8IE_REQUIRE(L && in, "null argument");
   I8IE_REQUIRE(out != nullptr || (out_f32 != nullptr && !L->conv), "null output");
   I8IE_REQUIRE(m > 0, "non-positive batch");
-  I8IE_REQUIRE((in_layout == I8IE_LAYOUT_NCHW || in_layout == I8IE_LAYOUT_NHWC) &&
-                   (out_layout == I8IE_LAYOUT_NCHW || out_layout == I8IE_LAYOUT_NHWC),
+  I8IE_REQUIRE(in_layout >= I8IE_LAYOUT_NCHW && in_layout <= I8IE_LAYOUT_NHWC_S8 && out_layout >= I8IE_LAYOUT_NCHW &&
+                   out_layout <= I8IE_LAYOUT_NHWC_S8,
                "bad layout tag");
+  I8IE_REQUIRE(L->conv || (in_layout != I8IE_LAYOUT_NHWC_S8 && out_layout != I8IE_LAYOUT_NHWC_S8),
+               "the re-biased layout applies to conv layers only");
   I8IE_REQUIRE(in_border >= 0 && out_border >= 0, "negative border");
-  I8IE_REQUIRE(in_layout == I8IE_LAYOUT_NHWC || in_border == 0, "only NHWC tensors carry a border");
-  I8IE_REQUIRE(out_layout == I8IE_LAYOUT_NHWC || out_border == 0, "only NHWC tensors carry a border");
+  I8IE_REQUIRE(in_layout != I8IE_LAYOUT_NCHW || in_border == 0, "only NHWC tensors carry a border");
+  I8IE_REQUIRE(out_layout != I8IE_LAYOUT_NCHW || out_border == 0, "only NHWC tensors carry a border");
   i8ie_ctx* ctx = L->ctx;
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
   I8IE_TRY(ensure_offsets(L, s_in, zp_in));
@@ -631,32 +647,63 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
   ConvGeom cg;
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
   const bool pool = pool_k > 1 || (pool_k == 1 && pool_s > 1);
-  if (pool) {
-    I8IE_REQUIRE(pool_k <= cg.oh && pool_k <= cg.ow, "max-pool window larger than the convolution's output");
-    if (!stem_takes(L, cg, pool_k, pool_s)) {
-      // no kernel fuses this pool: max_pool2d<u8> (src/functional.cc:36-64) as its own launch behind the convolution
-      const int ph = (cg.oh - pool_k) / pool_s + 1, pw = (cg.ow - pool_k) / pool_s + 1;
-      const bool nhwc = out_layout == I8IE_LAYOUT_NHWC && L->n % 16 == 0;
-      uint8_t* tmp = nullptr;
-      I8IE_TRY(i8ie_malloc(ctx, (size_t)m * L->n * cg.oh * cg.ow, (void**)&tmp));
-      int rc = layer_forward_impl(L, in, in_layout, in_border, m, h, w, s_in, zp_in, relu, 0, 0, tmp,
-                                  nhwc ? I8IE_LAYOUT_NHWC : I8IE_LAYOUT_NCHW, 0, acc, nullptr);
-      if (rc == I8IE_OK) {
-        if (nhwc) {
-          rc = i8ie_launch_maxpool_nhwc(ctx, tmp, 0, out, out_border, m, L->n, cg.oh, cg.ow, pool_k, pool_s, 0);
-        } else if (out_layout == I8IE_LAYOUT_NCHW) {
-          rc = i8ie_maxpool2d_u8(ctx, tmp, out, m, L->n, cg.oh, cg.ow, pool_k, pool_s);
-        } else {  // NHWC result with channels % 16 != 0: pool in NCHW, then lay out
-          uint8_t* tmp2 = nullptr;
-          rc = i8ie_malloc(ctx, (size_t)m * L->n * ph * pw, (void**)&tmp2);
-          if (rc == I8IE_OK) rc = i8ie_maxpool2d_u8(ctx, tmp, tmp2, m, L->n, cg.oh, cg.ow, pool_k, pool_s);
-          if (rc == I8IE_OK) rc = i8ie_launch_nchw_to_nhwc(ctx, tmp2, out, m, L->n, ph, pw, out_border);
-          i8ie_free(ctx, tmp2);
-        }
+  if (pool) I8IE_REQUIRE(pool_k <= cg.oh && pool_k <= cg.ow, "max-pool window larger than the convolution's output");
+  const bool in_s8 = in_layout == I8IE_LAYOUT_NHWC_S8, out_s8 = out_layout == I8IE_LAYOUT_NHWC_S8;
+  // Which kernel folds what: the first-stage kernel (path B) pools and can store re-biased; the patch-stationary kernel
+  // (path A) pools, reads and stores re-biased -- when it takes the launch at all (batch, geometry, LDS: asked below).
+  // Everything else: the plain call, with the pool / the re-bias as launches of their own around it.
+  const bool stem = stem_takes(L, cg, pool ? pool_k : 0, pool_s) && (acc == nullptr || aligned16(acc));
+  bool pconv = false;
+  if (!stem && (pool || in_s8 || out_s8) && out_layout != I8IE_LAYOUT_NCHW && aligned16(in) && aligned16(out) &&
+      (acc == nullptr || aligned16(acc)))
+    pconv = pconv_probe(L, cg, m, in_border, pool ? pool_k : 0, pool_s, in_s8, out_s8);
+  if (in_s8 && !pconv) {  // nobody reads the re-biased bytes as they are: plain copy first
+    const size_t bytes = (size_t)m * (cg.h + 2 * in_border) * (cg.w + 2 * in_border) * cg.c;
+    uint8_t* tmp = nullptr;
+    I8IE_TRY(i8ie_malloc(ctx, bytes, (void**)&tmp));
+    int rc = i8ie_rebias_u8(ctx, in, tmp, (int64_t)bytes);
+    if (rc == I8IE_OK)
+      rc = layer_forward_impl(L, tmp, I8IE_LAYOUT_NHWC, in_border, m, h, w, s_in, zp_in, relu, pool_k, pool_s, out, out_layout,
+                              out_border, acc, nullptr);
+    i8ie_free(ctx, tmp);
+    return rc;
+  }
+  if (out_s8 && !pconv && !stem) {  // plain result into a temporary, re-biased, then laid into `out` with its border
+    const int oph = pool ? (cg.oh - pool_k) / pool_s + 1 : cg.oh, opw = pool ? (cg.ow - pool_k) / pool_s + 1 : cg.ow;
+    const size_t bytes = (size_t)m * L->n * oph * opw;
+    I8IE_REQUIRE(L->n % 16 == 0, "re-biased NHWC output needs out features % 16 == 0");
+    uint8_t* tmp = nullptr;
+    I8IE_TRY(i8ie_malloc(ctx, bytes, (void**)&tmp));
+    int rc = layer_forward_impl(L, in, in_layout, in_border, m, h, w, s_in, zp_in, relu, pool_k, pool_s, tmp, I8IE_LAYOUT_NHWC, 0,
+                                acc, nullptr);
+    if (rc == I8IE_OK) rc = i8ie_rebias_u8(ctx, tmp, tmp, (int64_t)bytes);
+    if (rc == I8IE_OK) rc = i8ie_launch_reborder(ctx, tmp, out, m, L->n, oph, opw, 0, out_border, L->zp_out ^ 0x80);
+    i8ie_free(ctx, tmp);
+    return rc;
+  }
+  if (pool && !stem && !pconv) {
+    // no kernel fuses this pool: max_pool2d<u8> (src/functional.cc:36-64) as its own launch behind the convolution
+    const int oph = (cg.oh - pool_k) / pool_s + 1, opw = (cg.ow - pool_k) / pool_s + 1;
+    const bool nhwc = out_layout == I8IE_LAYOUT_NHWC && L->n % 16 == 0;
+    uint8_t* tmp = nullptr;
+    I8IE_TRY(i8ie_malloc(ctx, (size_t)m * L->n * cg.oh * cg.ow, (void**)&tmp));
+    int rc = layer_forward_impl(L, in, in_layout, in_border, m, h, w, s_in, zp_in, relu, 0, 0, tmp,
+                                nhwc ? I8IE_LAYOUT_NHWC : I8IE_LAYOUT_NCHW, 0, acc, nullptr);
+    if (rc == I8IE_OK) {
+      if (nhwc) {
+        rc = i8ie_launch_maxpool_nhwc(ctx, tmp, 0, out, out_border, m, L->n, cg.oh, cg.ow, pool_k, pool_s, 0);
+      } else if (out_layout == I8IE_LAYOUT_NCHW) {
+        rc = i8ie_maxpool2d_u8(ctx, tmp, out, m, L->n, cg.oh, cg.ow, pool_k, pool_s);
+      } else {  // NHWC result with channels % 16 != 0: pool in NCHW, then lay out
+        uint8_t* tmp2 = nullptr;
+        rc = i8ie_malloc(ctx, (size_t)m * L->n * oph * opw, (void**)&tmp2);
+        if (rc == I8IE_OK) rc = i8ie_maxpool2d_u8(ctx, tmp, tmp2, m, L->n, cg.oh, cg.ow, pool_k, pool_s);
+        if (rc == I8IE_OK) rc = i8ie_launch_nchw_to_nhwc(ctx, tmp2, out, m, L->n, oph, opw, out_border);
+        i8ie_free(ctx, tmp2);
       }
-      i8ie_free(ctx, tmp);
-      return rc;
     }
+    i8ie_free(ctx, tmp);
+    return rc;
   }
   const int ph = pool ? (cg.oh - pool_k) / pool_s + 1 : cg.oh, pw = pool ? (cg.ow - pool_k) / pool_s + 1 : cg.ow;
   const size_t in_bytes = (size_t)m * cg.c * cg.h * cg.w;
@@ -692,11 +739,14 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
   c.biasf = nullptr; c.wcache = &L->wc;
   c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
   c.acc = acc; c.Ktrue = cg.K; c.OH = cg.oh; c.OW = cg.ow;
+  if (pconv) {  // (the patch-stationary kernel said it takes this launch as it is)
+    c.pool_k = pool ? pool_k : 0; c.pool_s = pool_s; c.a_s8 = in_s8 ? 1 : 0; c.out_s8 = out_s8 ? 1 : 0;
+  }
   const size_t o_bytes = out_layout == I8IE_LAYOUT_NCHW ? i8ie_align_up(out_bytes, 256) : 0;
 
   if (path == PATH_A) {
     const int Hp = cg.h + 2 * cg.pad, Wp = cg.w + 2 * cg.pad;
-    const bool direct = in_layout == I8IE_LAYOUT_NHWC && in_border >= cg.pad && aligned16(in);
+    const bool direct = in_layout != I8IE_LAYOUT_NCHW && in_border >= cg.pad && aligned16(in);
     const size_t a_bytes = direct ? 0 : i8ie_align_up((size_t)m * Hp * Wp * cg.c, 256);
     I8IE_TRY(i8ie_ws_reserve(ctx, a_bytes + o_bytes + 256));
     uint8_t* ws = (uint8_t*)ctx->ws;
@@ -707,8 +757,8 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
       c.a_bytes = (size_t)m * iHp * iWp * cg.c - shift;
       c.Hp = iHp; c.Wp = iWp;
     } else {
-      if (in_layout == I8IE_LAYOUT_NHWC) {
-        I8IE_TRY(i8ie_launch_reborder(ctx, in, ws, m, cg.c, cg.h, cg.w, in_border, cg.pad, zp_in));
+      if (in_layout != I8IE_LAYOUT_NCHW) {  // (re-biased bytes are copied as they are; their border value is zp ^ 0x80)
+        I8IE_TRY(i8ie_launch_reborder(ctx, in, ws, m, cg.c, cg.h, cg.w, in_border, cg.pad, in_s8 ? (zp_in ^ 0x80) : zp_in));
       } else {
         if (cg.pad > 0) I8IE_HIP_TRY(hipMemsetAsync(ws, zp_in, (size_t)m * Hp * Wp * cg.c, ctx->stream));
         I8IE_TRY(i8ie_launch_nchw_to_nhwc(ctx, in, ws, m, cg.c, cg.h, cg.w, cg.pad));
@@ -722,9 +772,9 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
   } else {  // PATH_B: small-C, stride % 4 == 0
     const int Hp = (cg.oh - 1) * cg.stride + cg.kh;
     const int Wg = (cg.ow - 1) * (cg.stride / 4) + L->kwg;
-    const size_t t_bytes = in_layout == I8IE_LAYOUT_NHWC ? i8ie_align_up(in_bytes, 256) : 0;
+    const size_t t_bytes = in_layout != I8IE_LAYOUT_NCHW ? i8ie_align_up(in_bytes, 256) : 0;
     const size_t r_bytes = i8ie_align_up((size_t)m * Hp * Wg * 16, 256);
-    if (stem_takes(L, cg, pool ? pool_k : 0, pool_s) && (acc == nullptr || aligned16(acc))) {
+    if (stem && (acc == nullptr || aligned16(acc))) {
       // first-stage kernel (i8ie_stem.hip): space-to-depth image, conv (+ relu) (+ max-pool) in one contraction launch
       const size_t s_bytes = i8ie_align_up(i8ie_stem_scratch_bytes(m, cg.kh, cg.kw, cg.stride, cg.oh, cg.ow), 256);
       I8IE_TRY(i8ie_ws_reserve(ctx, t_bytes + s_bytes + o_bytes + 256));
@@ -742,7 +792,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
       f.B = L->Bstem; f.Kpad = L->KpadStem; f.N = L->n; f.ocp = L->ocp;
       f.s_in = s_in; f.s_w = L->s_w; f.s_out = L->s_out; f.zp_out = L->zp_out; f.relu = relu;
       f.pool_k = pool ? pool_k : 0; f.pool_s = pool_s;
-      f.out = dst; f.ob = o_bytes ? 0 : out_border; f.out_s8 = 0; f.acc = acc;
+      f.out = dst; f.ob = o_bytes ? 0 : out_border; f.out_s8 = out_s8 ? 1 : 0; f.acc = acc;
       I8IE_TRY(i8ie_stem_launch(ctx, f));
       if (o_bytes) I8IE_TRY(i8ie_launch_nhwc_to_nchw(ctx, dst, out, m, cg.kc, ph, pw, 0));
       return I8IE_OK;
@@ -794,20 +844,36 @@ int i8ie_layer_accepts_f32_input(const i8ie_layer* L, int h, int w, int* yes) {
   return I8IE_OK;
 }
 
-int i8ie_layer_fuses_pool(const i8ie_layer* L, int h, int w, int pool_k, int pool_s, int* yes) {
+int i8ie_layer_fuses_pool(const i8ie_layer* L, int m, int h, int w, int pool_k, int pool_s, int* yes) {
   I8IE_REQUIRE(L && yes, "null argument");
   *yes = 0;
-  if (!L->conv || pool_k < 1 || pool_s < 1) return I8IE_OK;
+  if (!L->conv || pool_k < 1 || pool_s < 1 || m < 1) return I8IE_OK;
   ConvGeom cg;
   if (conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg) != I8IE_OK) return I8IE_OK;
   if (pool_k > cg.oh || pool_k > cg.ow) return I8IE_OK;
-  *yes = stem_takes(L, cg, pool_k, pool_s) ? 1 : 0;
+  *yes = (stem_takes(L, cg, pool_k, pool_s) || pconv_probe(const_cast<i8ie_layer*>(L), cg, m, cg.pad, pool_k, pool_s, false, false)) ? 1 : 0;
+  return I8IE_OK;
+}
+
+int i8ie_layer_rebiased_io(const i8ie_layer* L, int m, int h, int w, int pool_k, int pool_s, int* reads, int* stores) {
+  I8IE_REQUIRE(L && reads && stores, "null argument");
+  *reads = *stores = 0;
+  if (!L->conv || m < 1) return I8IE_OK;
+  ConvGeom cg;
+  if (conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg) != I8IE_OK) return I8IE_OK;
+  const bool pool = pool_k > 1;
+  if (pool && (pool_s < 1 || pool_k > cg.oh || pool_k > cg.ow)) return I8IE_OK;
+  i8ie_layer* Lm = const_cast<i8ie_layer*>(L);
+  *reads = pconv_probe(Lm, cg, m, cg.pad, pool ? pool_k : 0, pool_s, true, false) ? 1 : 0;
+  *stores = (stem_takes(L, cg, pool ? pool_k : 0, pool_s) || pconv_probe(Lm, cg, m, cg.pad, pool ? pool_k : 0, pool_s, false, true)) ? 1 : 0;
   return I8IE_OK;
 }
 
 int i8ie_layer_forward_f32_input_pool(i8ie_layer* L, const float* in, int m, int h, int w, float q_scale, uint8_t q_zp,
-                                      int relu, int pool_k, int pool_s, uint8_t* out, int out_border, int32_t* acc) {
+                                      int relu, int pool_k, int pool_s, uint8_t* out, int out_layout, int out_border,
+                                      int32_t* acc) {
   I8IE_REQUIRE(L && in && out, "null argument");
+  I8IE_REQUIRE(out_layout == I8IE_LAYOUT_NHWC || out_layout == I8IE_LAYOUT_NHWC_S8, "the fused first layer writes NHWC (plain or re-biased)");
   I8IE_REQUIRE(m > 0 && out_border >= 0, "bad argument");
   int yes = 0;
   I8IE_TRY(i8ie_layer_accepts_f32_input(L, h, w, &yes));
@@ -835,16 +901,30 @@ int i8ie_layer_forward_f32_input_pool(i8ie_layer* L, const float* in, int m, int
     f.B = L->Bstem; f.Kpad = L->KpadStem; f.N = L->n; f.ocp = L->ocp;
     f.s_in = q_scale; f.s_w = L->s_w; f.s_out = L->s_out; f.zp_out = L->zp_out; f.relu = relu;
     f.pool_k = pool ? pool_k : 0; f.pool_s = pool_s;
-    f.out = out; f.ob = out_border; f.out_s8 = 0; f.acc = acc;
+    f.out = out; f.ob = out_border; f.out_s8 = out_layout == I8IE_LAYOUT_NHWC_S8 ? 1 : 0; f.acc = acc;
     return i8ie_stem_launch(ctx, f);
   }
-  if (pool) {  // the older first-layer kernel does not pool: conv (+ relu) into a temporary, then max_pool2d<u8> on NHWC
+  if (pool || out_layout == I8IE_LAYOUT_NHWC_S8) {
+    // the older first-layer kernel neither pools nor stores re-biased: conv (+ relu) into a temporary, then the rest
     I8IE_REQUIRE(L->n % 16 == 0, "i8ie_layer_forward_f32_input_pool: out features % 16 != 0");
-    uint8_t* tmp = nullptr;
+    const int oph = pool ? (cg.oh - pool_k) / pool_s + 1 : cg.oh, opw = pool ? (cg.ow - pool_k) / pool_s + 1 : cg.ow;
+    uint8_t *tmp = nullptr, *tmp2 = nullptr;
     I8IE_TRY(i8ie_malloc(ctx, (size_t)m * L->n * cg.oh * cg.ow, (void**)&tmp));
-    int rc = i8ie_layer_forward_f32_input_pool(L, in, m, h, w, q_scale, q_zp, relu, 0, 0, tmp, 0, acc);
-    if (rc == I8IE_OK) rc = i8ie_launch_maxpool_nhwc(ctx, tmp, 0, out, out_border, m, L->n, cg.oh, cg.ow, pool_k, pool_s, 0);
+    int rc = i8ie_layer_forward_f32_input_pool(L, in, m, h, w, q_scale, q_zp, relu, 0, 0, tmp, I8IE_LAYOUT_NHWC, 0, acc);
+    if (rc == I8IE_OK && out_layout == I8IE_LAYOUT_NHWC) {
+      rc = i8ie_launch_maxpool_nhwc(ctx, tmp, 0, out, out_border, m, L->n, cg.oh, cg.ow, pool_k, pool_s, 0);
+    } else if (rc == I8IE_OK) {
+      uint8_t* plain = tmp;
+      if (pool) {
+        rc = i8ie_malloc(ctx, (size_t)m * L->n * oph * opw, (void**)&tmp2);
+        if (rc == I8IE_OK) rc = i8ie_launch_maxpool_nhwc(ctx, tmp, 0, tmp2, 0, m, L->n, cg.oh, cg.ow, pool_k, pool_s, 0);
+        plain = tmp2;
+      }
+      if (rc == I8IE_OK) rc = i8ie_rebias_u8(ctx, plain, plain, (int64_t)m * L->n * oph * opw);
+      if (rc == I8IE_OK) rc = i8ie_launch_reborder(ctx, plain, out, m, L->n, oph, opw, 0, out_border, L->zp_out ^ 0x80);
+    }
     i8ie_free(ctx, tmp);
+    if (tmp2) i8ie_free(ctx, tmp2);
     return rc;
   }
   I8IE_TRY(i8ie_ws_reserve(ctx, i8ie_first_scratch_bytes(m, cg.kh, L->kwg, cg.stride, cg.oh, cg.ow) + 256));
@@ -860,7 +940,7 @@ int i8ie_layer_forward_f32_input_pool(i8ie_layer* L, const float* in, int m, int
 
 int i8ie_layer_forward_f32_input(i8ie_layer* L, const float* in, int m, int h, int w, float q_scale, uint8_t q_zp,
                                  int relu, uint8_t* out, int out_border, int32_t* acc) {
-  return i8ie_layer_forward_f32_input_pool(L, in, m, h, w, q_scale, q_zp, relu, 0, 0, out, out_border, acc);
+  return i8ie_layer_forward_f32_input_pool(L, in, m, h, w, q_scale, q_zp, relu, 0, 0, out, I8IE_LAYOUT_NHWC, out_border, acc);
 }
 
 int i8ie_layer_forward(i8ie_layer* L, const uint8_t* in, int m, int h, int w, float s_in, uint8_t zp_in, uint8_t* out,

@@ -47,6 +47,7 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr unsigned kRowInvalid = 0xC0000000u;  // beyond any output buffer this kernel accepts (< 2^31 bytes)
 constexpr int kTabPix = 256;                   // pixels per tile at most (16 MFMA row tiles)
@@ -79,6 +80,14 @@ struct PCArgs {
   int split;                // 1: a (band, feature pass) pair is a unit of its own (small batches: more units than CUs)
   int flags;                // 1 = weights of the next pass fetched by the last K tile (not with split)
   int32_t* acc;             // ACC kernels: [M][N] pre-requant accumulators (the cblas_gemm_s8u8s32 result, src/conv2d.cc:131-133)
+  int a_s8;                 // 1: the input bytes are stored re-biased already (I8IE_LAYOUT_NHWC_S8): no xor pass over the patch
+  unsigned xor_out;         // 0x80808080: the output is stored re-biased (I8IE_LAYOUT_NHWC_S8), else 0
+  // POOL kernels: max_pool2d (pk x pk, stride ps) behind the (relu'd) convolution.  `out` is then the POOLED tensor
+  // [n][PH + 2 ob][PW + 2 ob][N]; the requantised rows of a band go to an LDS ring of RB conv rows (pixel pitch opitch),
+  // and the bands of an image run back to back in one block (seq) so that the rows a window shares with the previous
+  // band are still there
+  int pk, ps, PH, PW, RB, opitch, lds_otile, seq;
+  float rcpPW, rcpC16, rcpRB;
   unsigned long long* dbg;  // diagnostic build, variant 51: per block, cycles spent per phase (wave 0); null otherwise
 };
 
@@ -109,7 +118,8 @@ __device__ __forceinline__ int pc_row_to_pix(int r) { return (r < 4) ? 2 * r : (
 // TMW: 16-pixel MFMA tiles per wave (2 waves along the pixels); NTW: 16-feature tiles per wave (4 waves along the
 // features, block = 64 NTW features per pass)
 // ACC: also dump the INT32 accumulators (acc_dbg of the C-ABI) -- a separate instantiation, the default one is untouched
-template <int TMW, int NTW, bool ACC>
+// POOL: max-pool folded in behind the requantiser (PCArgs::pk ...)
+template <int TMW, int NTW, bool ACC, bool POOL>
 __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   uint8_t* const smem = pc_smem;
   constexpr int BN = NTW * 64;
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   // ---- tiles of this block: XCD-contiguous ranges, consecutive tiles to the blocks of one XCD
   const int per = (int)gridDim.x >> 3;
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int n_units = p.split ? p.n_tiles * p.npass : p.n_tiles;
+  const int n_units = p.seq ? p.n_tiles / p.bands : (p.split ? p.n_tiles * p.npass : p.n_tiles);  // (seq: a unit is an image)
   const int Tx = (n_units + 7) >> 3;
   const int t_lo = xcd * Tx;
   const int t_hi = t_lo + Tx < n_units ? t_lo + Tx : n_units;
@@ -186,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
     }
   };
   auto patch_xor = [&](int dst) {  // every lane re-biases exactly the granules it fetched itself
+    if (p.a_s8) return;            // (the producer stored the bytes re-biased: nothing to do)
     for (int g = tid; g < p.patch_gran; g += 512) {
       v4i* q = reinterpret_cast<v4i*>(smem + dst + g * 16);
       *q = *q ^ (int)0x80808080;
@@ -252,21 +263,102 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
             *reinterpret_cast<v4i*>(p.acc + ((size_t)img * (size_t)(p.OH * p.OW) + (size_t)(oy0 * p.OW + pi)) * (size_t)p.N + col) = acc[mi][ni];
         }
       }
+      if constexpr (POOL) {
+        // requantised bytes -> the LDS ring of conv rows: pixel L = slot0 * OW + pi of a ring of RB * OW pixels (rows of a
+        // band are contiguous in it; only the ring's end wraps).  16 lanes = 16 different pixels, 272-byte pitch:
+        // conflict-free ds_write_b64
+        int L = (oy0 % p.RB) * p.OW + pi;
+        if (L >= p.RB * p.OW) L -= p.RB * p.OW;
+        uint8_t* const orow = smem + p.lds_otile + L * p.opitch;
 #pragma unroll
-      for (int ni = 0; ni + 1 < NTW; ni += 2) {
-        // rows of 16 lanes: odd rows of d[ni] <-> even rows of d[ni + 1]: every lane then holds 8 consecutive features
-        const auto sw = __builtin_amdgcn_permlane16_swap(d[ni], d[ni + 1], false, false);
-        const int col = n0 + ni * 16 + 16 * (lq & 1) + 8 * (lq >> 1);
-        v2u val;
-        val.x = sw[0];
-        val.y = sw[1];
-        __builtin_amdgcn_raw_buffer_store_b64(val, rsO, (int)((col < p.N && rowoff != kRowInvalid) ? rowoff + (unsigned)col : kRowInvalid), 0, 0);
-      }
-      if (NTW & 1) {  // the odd last feature tile: 4 features per lane
-        const int col = n0 + (NTW - 1) * 16 + 4 * lq;
-        __builtin_amdgcn_raw_buffer_store_b32(d[NTW - 1], rsO, (int)((col < p.N && rowoff != kRowInvalid) ? rowoff + (unsigned)col : kRowInvalid), 0, 0);
+        for (int ni = 0; ni + 1 < NTW; ni += 2) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(d[ni], d[ni + 1], false, false);
+          const int col = n0 + ni * 16 + 16 * (lq & 1) + 8 * (lq >> 1);
+          v2u val;
+          val.x = sw[0];
+          val.y = sw[1];
+          if (pi < valid && col < p.N) *reinterpret_cast<v2u*>(orow + col) = val;
+        }
+        if (NTW & 1) {
+          const int col = n0 + (NTW - 1) * 16 + 4 * lq;
+          if (pi < valid && col < p.N) *reinterpret_cast<uint32_t*>(orow + col) = d[NTW - 1];
+        }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni + 1 < NTW; ni += 2) {
+          // rows of 16 lanes: odd rows of d[ni] <-> even rows of d[ni + 1]: every lane then holds 8 consecutive features
+          const auto sw = __builtin_amdgcn_permlane16_swap(d[ni], d[ni + 1], false, false);
+          const int col = n0 + ni * 16 + 16 * (lq & 1) + 8 * (lq >> 1);
+          v2u val;
+          val.x = sw[0] ^ p.xor_out;
+          val.y = sw[1] ^ p.xor_out;
+          __builtin_amdgcn_raw_buffer_store_b64(val, rsO, (int)((col < p.N && rowoff != kRowInvalid) ? rowoff + (unsigned)col : kRowInvalid), 0, 0);
+        }
+        if (NTW & 1) {  // the odd last feature tile: 4 features per lane
+          const int col = n0 + (NTW - 1) * 16 + 4 * lq;
+          __builtin_amdgcn_raw_buffer_store_b32(d[NTW - 1] ^ p.xor_out, rsO, (int)((col < p.N && rowoff != kRowInvalid) ? rowoff + (unsigned)col : kRowInvalid), 0, 0);
+        }
       }
     }
+  };
+
+  // ---- POOL: pooled rows [j0, j1) of image img from the LDS ring -> the output tensor.  Thread = (pooled row, pooled
+  //      pixel, 16 features): pk x pk ds_read_b128, byte maxima as two v_pk_max_u16 per dword (even / odd bytes spread
+  //      by v_perm_b32), one 16-byte store.  Returns the number of store instructions this wave issued.
+  auto pool_pass = [&](int img, int j0, int j1) {
+    const int C16 = p.N >> 4;
+    const int tasks = (j1 - j0) * p.PW * C16;
+    const int PHp = p.PH + 2 * p.ob, PWp = p.PW + 2 * p.ob;
+    int nst = 0;
+    for (int id0 = 0; id0 < tasks; id0 += 512) {
+      const int id = id0 + tid;
+      if (id0 + wave * 64 < tasks) ++nst;  // (this wave executes the store below: at least its first lane has a task)
+      if (id < tasks) {
+        int t1, c16, jr, px;
+        pc_divmod(id, C16, p.rcpC16, t1, c16);
+        pc_divmod(t1, p.PW, p.rcpPW, jr, px);
+        const int j = j0 + jr;
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        us2 me[4], mo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          me[q] = us2{0, 0};
+          mo[q] = us2{0, 0};
+        }
+        int rq0, r0;
+        pc_divmod(j * p.ps, p.RB, p.rcpRB, rq0, r0);  // first conv row of the window -> ring row
+        for (int dy = 0; dy < p.pk; ++dy) {
+          int r = r0 + dy;
+          if (r >= p.RB) r -= p.RB;
+          const uint8_t* rowp = smem + p.lds_otile + (r * p.OW + px * p.ps) * p.opitch + c16 * 16;
+          for (int dx = 0; dx < p.pk; ++dx) {
+            const v4i v = *reinterpret_cast<const v4i*>(rowp + dx * p.opitch);
+            const uint32_t w4[4] = {(uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const us2 e = __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w4[q], 0x0c020c00u));  // [b0, 0, b2, 0]
+              const us2 o = __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w4[q], 0x0c030c01u));  // [b1, 0, b3, 0]
+              me[q] = __builtin_elementwise_max(me[q], e);
+              mo[q] = __builtin_elementwise_max(mo[q], o);
+            }
+          }
+        }
+        uint32_t r4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          r4[q] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, mo[q]), __builtin_bit_cast(uint32_t, me[q]), 0x06020400u) ^ p.xor_out;
+        const unsigned off = ((unsigned)((img * PHp + j + p.ob) * PWp + px + p.ob)) * (unsigned)p.N + (unsigned)c16 * 16u;
+        v4u val;
+        val.x = r4[0]; val.y = r4[1]; val.z = r4[2]; val.w = r4[3];
+        __builtin_amdgcn_raw_buffer_store_b128(val, rsO, (int)off, 0, 0);
+      }
+    }
+    return nst;
+  };
+  auto rows_done = [&](int hi) {  // pooled rows whose window ends below conv row hi
+    if (hi < p.pk) return 0;
+    const int e = (hi - p.pk) / p.ps + 1;
+    return e < p.PH ? e : p.PH;
   };
 
   // =============================== tile loop ===========================================================
@@ -285,8 +377,13 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   const int lin_total = p.npass * p.nkt;
   const int patch = p.lds_patch;
   const bool xpre = (p.flags & 1) != 0;  // the last K tile of a pass already fetches the first weights of the next pass / band (+1 %)
-  auto tile_of = [&](int u) { return p.split ? u / p.npass : u; };
-  patch_fill(tile_of(unit), patch);
+  // The block's tiles, in order.  seq (POOL with several bands per image): a unit is an image and its bands follow each
+  // other here; otherwise a unit is a band (or a (band, pass) pair with split).
+  int band = 0;
+  auto tile_at = [&](int u, int b) { return p.seq ? u * p.bands + b : (p.split ? u / p.npass : u); };
+  auto has_next = [&](int u, int b) { return (p.seq && b + 1 < p.bands) || u + per < t_hi; };
+  auto next_tile = [&](int u, int b) { return (p.seq && b + 1 < p.bands) ? tile_at(u, b + 1) : tile_at(u + per, 0); };
+  patch_fill(tile_at(unit, 0), patch);
   pc_wait_vm<0>();
   patch_xor(patch);
   if (xpre) {
@@ -297,9 +394,9 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
 #if defined(I8IE_DIAG)
   if (p.dbg) tq = __builtin_amdgcn_s_memtime();
 #endif
-  for (; unit < t_hi; unit += per) {
-    const bool more = unit + per < t_hi;
-    const int tile = tile_of(unit);
+  while (unit < t_hi) {
+    const bool more = has_next(unit, band);
+    const int tile = tile_at(unit, band);
     const int pass_lo = p.split ? unit - tile * p.npass : 0, pass_hi = p.split ? pass_lo + 1 : p.npass;
     for (int pass = pass_lo; pass < pass_hi; ++pass) {
       int lin = pass * p.nkt;
@@ -347,11 +444,34 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
     // ---- hand-over: everyone is done with the patch -> request the next one -> it lands under the epilogue
     __syncthreads();
     stamp(2);  // waiting for the slowest wave's K loop
-    if (more) patch_fill(tile_of(unit + per), patch);
+    if (more) patch_fill(next_tile(unit, band), patch);
     stamp(3);  // issuing the patch DMA
     epilogue(tile, pass_hi - 1);
     stamp(1);
-    if (more) {
+    if constexpr (POOL) {
+      // the band's requantised rows are in the LDS ring: pool what they complete, under the landing patch
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (not __syncthreads(): the patch DMA and the ACC stores stay in flight)
+      const int img = tile / p.bands, bnd = tile - img * p.bands;
+      const int oy0 = bnd * p.RT;
+      const int hi = oy0 + p.RT < p.OH ? oy0 + p.RT : p.OH;
+      const int j0 = rows_done(oy0), j1 = rows_done(hi);
+      const int nst = j1 > j0 ? pool_pass(img, j0, j1) : 0;
+      if (more) {
+        // vector-memory operations retire in issue order: the patch DMA is older than the pool pass's stores (and, with
+        // ACC, younger than nothing that matters: ACC kernels just drain)
+        if (ACC) pc_wait_vm<0>();
+        else switch (nst) {
+          case 0: pc_wait_vm<0>(); break;
+          case 1: pc_wait_vm<1>(); break;
+          case 2: pc_wait_vm<2>(); break;
+          case 3: pc_wait_vm<3>(); break;
+          default: pc_wait_vm<4>(); break;
+        }
+        stamp(4);
+        patch_xor(patch);
+        stamp(5);
+      }
+    } else if (more) {
       pc_wait_vm<ST>();  // all but the epilogue's stores
       stamp(4);          // patch DMA not yet landed after the epilogue
       patch_xor(patch);
@@ -359,6 +479,12 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
     }
     __syncthreads();
     stamp(6);  // second barrier
+    if (p.seq && band + 1 < p.bands) {
+      ++band;
+    } else {
+      band = 0;
+      unit += per;
+    }
   }
   pc_wait_vm<0>();
 #if defined(I8IE_DIAG)
@@ -390,28 +516,37 @@ __global__ __launch_bounds__(256) void pconv_pack_kernel(const int8_t* __restric
   }
 }
 
-template <int TMW, int NTW, bool ACC>
-int launch_pc_acc(i8ie_ctx* ctx, const PCArgs& a, int grid, int lds) {
+template <int TMW, int NTW, bool ACC, bool POOL>
+int launch_pc_t(i8ie_ctx* ctx, const PCArgs& a, int grid, int lds) {
   static bool raised[64] = {};
   const int dev = ctx->device & 63;
   if (!raised[dev]) {
-    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<TMW, NTW, ACC>),
+    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pconv_kernel<TMW, NTW, ACC, POOL>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     raised[dev] = true;
   }
-  pconv_kernel<TMW, NTW, ACC><<<grid, 512, lds, ctx->stream>>>(a);
+  pconv_kernel<TMW, NTW, ACC, POOL><<<grid, 512, lds, ctx->stream>>>(a);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
 }
 template <int TMW, int NTW>
 int launch_pc(i8ie_ctx* ctx, const PCArgs& a, int grid, int lds) {
-  return a.acc != nullptr ? launch_pc_acc<TMW, NTW, true>(ctx, a, grid, lds) : launch_pc_acc<TMW, NTW, false>(ctx, a, grid, lds);
+  if (a.pk > 1)
+    return a.acc != nullptr ? launch_pc_t<TMW, NTW, true, true>(ctx, a, grid, lds) : launch_pc_t<TMW, NTW, false, true>(ctx, a, grid, lds);
+  return a.acc != nullptr ? launch_pc_t<TMW, NTW, true, false>(ctx, a, grid, lds) : launch_pc_t<TMW, NTW, false, false>(ctx, a, grid, lds);
 }
 
 }  // namespace
 
-int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
+static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry);
+int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) { return pconv_impl(ctx, c, false); }
+// would i8ie_pconv_try_launch take this call (incl. its max-pool)?  Nothing is launched or packed.
+int i8ie_pconv_takes(i8ie_ctx* ctx, const I8ieIgemmCall& c) { return pconv_impl(ctx, c, true); }
+
+static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   if (c.amode != 1 || c.biasf != nullptr || c.wcache == nullptr) return 0;
+  const bool pool = c.pool_k > 1;
+  if (pool && (c.pool_k > 3 || c.pool_s < 1 || c.pool_s > c.pool_k || c.pool_k > c.OH || c.pool_k > c.OW || c.N % 16 != 0)) return 0;
   if (c.acc != nullptr && ((reinterpret_cast<uintptr_t>(c.acc) & 15u) != 0 || c.N % 4 != 0)) return 0;  // (16-byte accumulator stores)
   if (c.N % 16 != 0 || c.N < 192 || c.Npad > 1024 || c.C < 32 || c.C % 32 != 0 || c.sh != c.sw) return 0;
   if ((reinterpret_cast<uintptr_t>(c.out) & 15u) != 0) return 0;
@@ -517,12 +652,16 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   }
   const int nkt = (int)perm.size() / 8;
   if (nkt < 2 || patch_gran >= (1 << 22)) return 0;
-  const size_t out_pixels = (size_t)n_img * (c.OH + 2 * c.ob) * (c.OW + 2 * c.ob);
+  const int PHo = pool ? (c.OH - c.pool_k) / c.pool_s + 1 : c.OH, PWo = pool ? (c.OW - c.pool_k) / c.pool_s + 1 : c.OW;
+  const size_t out_pixels = (size_t)n_img * (PHo + 2 * c.ob) * (PWo + 2 * c.ob);
   const size_t out_bytes = out_pixels * (size_t)c.N;
   if (out_bytes >= ((size_t)1 << 31) || c.a_bytes >= ((size_t)1 << 32) - 4096) return 0;
-  // LDS plan: [patch] [oc'] [tables]
+  // LDS plan: [patch] [oc'] [tables] ([source offsets]) ([POOL: ring of requantised conv rows])
   const int kt_bytes = bn * 128;
-  const int fixed = npass * bn * 4 + 2 * kTabPix * 4 + nkt * 32 + 64;
+  const int RB = bands > 1 ? RT + c.pool_k - 1 : c.OH;  // (rows a window shares with the band before stay in the ring)
+  const int opitch = c.N + 16;
+  const int otile = pool ? (RB * c.OW * opitch + 15) / 16 * 16 : 0;
+  const int fixed = npass * bn * 4 + 2 * kTabPix * 4 + nkt * 32 + 64 + otile;
   if (patch_gran * 16 + fixed > 160 * 1024) return 0;
   const bool src_tab = patch_gran * 16 + fixed + patch_gran * 4 <= 160 * 1024;
 
@@ -532,6 +671,9 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   const int n_tiles = n_img * bands;
   const int split = (n_tiles < grid && npass > 1) ? 1 : 0;
   if (ctx->variant == 0 && n_tiles * (split ? npass : 1) < grid * 3 / 4) return 0;
+  const int seq = (pool && bands > 1) ? 1 : 0;  // the bands of an image back to back in one block
+  if (pool && (split || (ctx->variant == 0 && n_img < grid * 3 / 4))) return 0;  // (pooling wants whole images per block)
+  if (dry) return 1;
 
   // ---- fragment-packed weights: once per layer and packing key, kept in the layer handle (I8ieWCache)
   // (a buffer holds [perm: nkt * 8 ints, padded to 256 B][weights]; the fragment order depends on the pass width)
@@ -584,6 +726,10 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.ob = c.ob; a.OHp = c.OH + 2 * c.ob; a.OWp = c.OW + 2 * c.ob;
   a.split = split;
   a.acc = c.acc;
+  a.a_s8 = c.a_s8;
+  a.xor_out = c.out_s8 ? 0x80808080u : 0u;
+  a.pk = pool ? c.pool_k : 1; a.ps = pool ? c.pool_s : 1; a.PH = PHo; a.PW = PWo; a.RB = RB; a.opitch = opitch; a.seq = seq;
+  a.rcpPW = 1.0f / (float)PWo; a.rcpC16 = 1.0f / (float)(c.N / 16 > 0 ? c.N / 16 : 1); a.rcpRB = 1.0f / (float)RB;
   a.flags = !split ? 1 : 0;
 #if defined(I8IE_DIAG)
   if (ctx->variant == 53) a.flags = 0;  // (weights fetched at the start of every pass)
@@ -594,14 +740,15 @@ int i8ie_pconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.lds_ktab = a.lds_tab + 2 * kTabPix * 4;
   a.lds_prog = a.lds_ktab + nkt * 32;
   a.lds_src = src_tab ? a.lds_prog + 64 : -1;
-  const int lds = a.lds_prog + 64 + (src_tab ? patch_gran * 4 : 0);
+  a.lds_otile = a.lds_prog + 64 + (src_tab ? patch_gran * 4 : 0);
+  const int lds = a.lds_otile + otile;
 
   const double ops = 2.0 * c.M * c.N * c.Ktrue;
   const double bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
   char tag[64];
-  snprintf(tag, sizeof(tag), "pconv_%dx%d|M%d,N%d,K%d", TMW * 32, bn, c.M, c.N, c.Kchunks * 16);
+  snprintf(tag, sizeof(tag), "pconv%s_%dx%d|M%d,N%d,K%d", pool ? "_pool" : "", TMW * 32, bn, c.M, c.N, c.Kchunks * 16);
   char nm[32];
-  snprintf(nm, sizeof(nm), "pconv_%dx%d", TMW * 32, bn);
+  snprintf(nm, sizeof(nm), "pconv%s_%dx%d", pool ? "_pool" : "", TMW * 32, bn);
   I8ieProfScope prof(ctx, ctx->prof ? tag : nm, ops, bytes);
 #if defined(I8IE_DIAG)
   static unsigned long long* dbg_dev[64] = {};  // per device

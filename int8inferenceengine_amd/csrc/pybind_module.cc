@@ -149,21 +149,29 @@ struct Storage {
   bool upload_block = false;       // `dev` belongs to upload_cache()
   bool external = false;           // `dev` is foreign HIP memory (e.g. a torch tensor's): never freed here
   py::object keep;                 // the pinned ndarray an asynchronous upload reads from / the foreign owner
-  int bzp = -1;  // >= 0: bordered NHWC buffer with border bytes == bzp (returns to border_cache)
+  int bzp = -1;  // >= 0: bordered NHWC buffer with border bytes == bzp, the physical byte (returns to border_cache)
   std::vector<unsigned char> host;
   bool host_valid = false;
   // physical layout of a 4-D u8 activation: the engine keeps NHWC between layers and
   // converts back to the reference's NCHW only when the bytes are observed
   int layout = I8IE_LAYOUT_NCHW;
   int border = 0;                      // NHWC only: physical border (pixels) holding the zero point
+  bool s8 = false;                     // NHWC only: bytes stored re-biased (^0x80, I8IE_LAYOUT_NHWC_S8; border: zp ^ 0x80)
   int dn = 0, dc = 0, dh = 0, dw = 0;  // logical NCHW dims, valid when layout == NHWC
   void set_nhwc(const std::vector<ssize_t>& shp, int b) {
     layout = I8IE_LAYOUT_NHWC;
     border = b;
     dn = (int)shp[0]; dc = (int)shp[1]; dh = (int)shp[2]; dw = (int)shp[3];
   }
+  void unbias() {  // re-biased bytes -> plain u8, in place (border bytes become the zero point again)
+    if (!s8 || !dev) return;
+    check(i8ie_rebias_u8(ctx(), (const uint8_t*)dev, (uint8_t*)dev, (int64_t)bytes));
+    s8 = false;
+    if (bzp >= 0) bzp ^= 0x80;
+  }
   void to_nchw() {
     if (layout == I8IE_LAYOUT_NCHW || external) return;
+    unbias();
     void* fresh = nullptr;
     const size_t logical = (size_t)dn * dc * dh * dw;
     check(i8ie_malloc(ctx(), logical, &fresh));
@@ -251,17 +259,21 @@ std::shared_ptr<Storage> device_storage(size_t bytes) {
   return s;
 }
 
-// NHWC u8 storage for logical shape `shp` (NCHW order) with a border of b pixels holding zp
-std::shared_ptr<Storage> nhwc_storage(const std::vector<ssize_t>& shp, int b, int zp) {
+// NHWC u8 storage for logical shape `shp` (NCHW order) with a border of b pixels holding zp (s8: the bytes of this
+// tensor are stored re-biased, I8IE_LAYOUT_NHWC_S8, so its border holds zp ^ 0x80)
+std::shared_ptr<Storage> nhwc_storage(const std::vector<ssize_t>& shp, int b, int zp, bool s8 = false) {
   const size_t bytes = (size_t)shp[0] * shp[1] * (shp[2] + 2 * b) * (shp[3] + 2 * b);
+  if (s8) zp ^= 0x80;
   if (b <= 0) {
     auto s = device_storage(bytes);
     s->set_nhwc(shp, 0);
+    s->s8 = s8;
     return s;
   }
   auto s = std::make_shared<Storage>();
   s->bytes = bytes;
   s->set_nhwc(shp, b);
+  s->s8 = s8;
   s->bzp = zp;
   auto it = border_cache().find(BorderKey{bytes, s->dn, s->dc, s->dh, s->dw, b, zp});
   if (it != border_cache().end() && !it->second.empty()) {
@@ -279,25 +291,28 @@ std::shared_ptr<Storage> nhwc_storage(const std::vector<ssize_t>& shp, int b, in
 // produced: a producer observed twice, or consumed by two ops, launches once per distinct (relu, border) request,
 // and its upstream chain (whose nodes cache in the same way) is never launched again.
 struct PendNode {
-  std::function<std::shared_ptr<Storage>(bool, int)> fn;
+  // arguments: fuse relu; physical border wanted by the consumer; consumer reads re-biased bytes (both honoured for NHWC
+  // results of layers whose kernel can; what came out is in the Storage)
+  std::function<std::shared_ptr<Storage>(bool, int, bool)> fn;
   // a conv layer whose kernel can fold a following max_pool2d into its epilogue (i8ie_layer_fuses_pool): arguments
   // relu, border of the POOLED result, pool kernel_size, stride; returns null when this launch cannot (the caller
   // then pools the unfused result)
-  std::function<std::shared_ptr<Storage>(bool, int, int, int)> fn_pool;
+  std::function<std::shared_ptr<Storage>(bool, int, bool, int, int)> fn_pool;
   struct Made {
     bool relu;
     int border;
     std::shared_ptr<Storage> st;
   };
   std::vector<Made> made;
-  std::shared_ptr<Storage> get(bool relu, int border) {
+  std::shared_ptr<Storage> get(bool relu, int border, bool s8 = false) {
     for (const Made& m : made)
       if (m.relu == relu && m.border == border && m.st) {
+        if (m.st->s8 && !s8) continue;  // (a plain reader does not take the re-biased copy)
         // a bordered NHWC result that was since converted in place (to_nchw) no longer has the border asked for
         if (border > 0 && (m.st->layout != I8IE_LAYOUT_NHWC || m.st->border != border)) continue;
         return m.st;
       }
-    std::shared_ptr<Storage> st = fn(relu, border);
+    std::shared_ptr<Storage> st = fn(relu, border, s8);
     made.push_back(Made{relu, border, st});
     return st;
   }
@@ -329,9 +344,9 @@ struct Tensor {
   float qscale = 0;
   u8_t qzp = 0;
 
-  void realize(int border = 0) {
+  void realize(int border = 0, bool s8 = false) {
     if (!pend) return;
-    st = pend->get(pend_relu, border);
+    st = pend->get(pend_relu, border, s8);
     pend.reset();
     pend_f32.reset();
     qsrc.reset();
@@ -349,8 +364,14 @@ struct Tensor {
     st->to_nchw();
     return static_cast<T*>(st->device_ptr());
   }
-  T* dptr_any() {  // whatever layout the storage is in (see st->layout)
+  T* dptr_any() {  // whatever layout the storage is in (see st->layout), plain bytes
     realize();
+    if (!st) throw std::runtime_error("i8ie: empty tensor");
+    T* p = static_cast<T*>(st->device_ptr());
+    st->unbias();
+    return p;
+  }
+  T* dptr_raw() {  // ... as it is, re-biased or not (st->s8): for consumers that take I8IE_LAYOUT_NHWC_S8
     if (!st) throw std::runtime_error("i8ie: empty tensor");
     return static_cast<T*>(st->device_ptr());
   }
@@ -593,7 +614,7 @@ Tensor<u8_t> quantize(Tensor<float>& in, float scale, u8_t zp) {  // src/quantiz
   out.qzp = zp;
   // deferred: a first conv layer that accepts FP32 input consumes `src` directly (fused quantize)
   out.pend = make_pend(
-      [src, n, scale, zp](bool relu, int) {
+      [src, n, scale, zp](bool relu, int, bool) {
         auto st = device_storage((size_t)n);
         check(i8ie_quantize_f32_u8(ctx(), (const float*)src->device_ptr(), (uint8_t*)st->dev, n, scale, zp));
         if (relu) check(i8ie_relu_u8(ctx(), (const uint8_t*)st->dev, (uint8_t*)st->dev, n, zp));
@@ -663,13 +684,13 @@ Tensor<u8_t> max_pool2d_u8(Tensor<u8_t>& in, ssize_t k, ssize_t s) {  // src/fun
   const int kk = (int)k, ss = (int)s;
   // deferred so that a consuming conv can ask for a zero-point border around the result
   out.pend = make_pend(
-      [src, ishp, oshp, zp, kk, ss](bool relu, int border) mutable {
+      [src, ishp, oshp, zp, kk, ss](bool relu, int border, bool s8) mutable {
         if (src.pend && src.pend->fn_pool && src.pend.use_count() == 1 && src.pend->made.empty()) {
           // relu(layer(x)) still pending, nobody else holds it (no second consumer, not observable any more), and its
           // kernel pools in the epilogue: one launch, no unpooled tensor.  With another holder the layer launches once,
           // unfused, and every consumer reads that result (a recorded launch never runs twice).
           // (a relu behind the pool folds in as well: max-pool and relu commute, both are monotone)
-          std::shared_ptr<Storage> st = src.pend->fn_pool(src.pend_relu || relu, border, kk, ss);
+          std::shared_ptr<Storage> st = src.pend->fn_pool(src.pend_relu || relu, border, s8, kk, ss);
           if (st) return st;
         }
         const uint8_t* ip = src.dptr_any();
@@ -921,76 +942,77 @@ class BaseLayer {
     const int zp_out = zero_point_;
     const std::vector<ssize_t> oshp = out.shape;
     const size_t obytes = (size_t)out.size;
-    out.pend = make_pend(
-        [handle, src, s_in, zp_in, zp_out, m, h, w, spatial, oshp, obytes](bool relu, int border) mutable {
-          int out_layout = I8IE_LAYOUT_NCHW, pad = 0;
-          if (spatial) {
-            check(i8ie_layer_preferred_layout(handle.get(), &out_layout));
-            check(i8ie_layer_padding(handle.get(), &pad));
-          }
-          if (spatial && out_layout == I8IE_LAYOUT_NHWC && src.pend && src.qsrc && !src.pend_relu) {
-            int yes = 0;
-            check(i8ie_layer_accepts_f32_input(handle.get(), h, w, &yes));
-            if (yes) {  // quantize + conv (+ relu) in one kernel, reading the FP32 input
-              auto st = nhwc_storage(oshp, border, zp_out);
-              check(i8ie_layer_forward_f32_input(handle.get(), (const float*)src.qsrc->device_ptr(), m, h, w,
-                                                 src.qscale, src.qzp, relu ? 1 : 0, (uint8_t*)st->dev, border, nullptr));
-              return st;
-            }
-          }
-          const uint8_t* ip;
-          if (spatial) {
-            // ask a still-pending producer for a zero-point border that covers this conv's padding
-            src.realize(out_layout == I8IE_LAYOUT_NHWC ? pad : 0);
-            ip = src.dptr_any();
-          } else {
-            src.realize(0);
-            Storage* s = src.st.get();
-            // x.reshape(n, -1) of an NHWC activation: the Linear layer walks K in (h, w, c) order instead
-            if (s && s->layout == I8IE_LAYOUT_NHWC && s->border == 0 && s->dn == m && s->dh * s->dw > 1 &&
-                (ssize_t)s->dn * s->dc * s->dh * s->dw == src.size) {
-              ip = src.dptr_any();
-              h = s->dh;
-              w = s->dw;
-            } else {
-              ip = src.dptr();
-            }
-          }
-          const int in_layout = src.st->layout, in_border = src.st->border;
-          const int ob = out_layout == I8IE_LAYOUT_NHWC ? border : 0;
-          auto st = out_layout == I8IE_LAYOUT_NHWC ? nhwc_storage(oshp, ob, zp_out) : device_storage(obytes);
-          check(i8ie_layer_forward_fused(handle.get(), ip, in_layout, in_border, m, h, w, s_in, zp_in, relu ? 1 : 0,
-                                         (uint8_t*)st->dev, out_layout, ob, nullptr));
-          // (the input is released when the last tensor holding this closure lets go of it: right after the
-          // launch in `x = relu(layer(x))`, later if the un-fused result is observed as well)
-          return st;
-        });
-    if (spatial) {
-      Tensor<u8_t> srcp = in;
-      out.pend->fn_pool = [handle, srcp, s_in, zp_in, zp_out, m, h, w, oshp](bool relu, int border, int pk, int ps) mutable
-          -> std::shared_ptr<Storage> {
-        int yes = 0, out_layout = I8IE_LAYOUT_NCHW, pad = 0;
-        check(i8ie_layer_fuses_pool(handle.get(), h, w, pk, ps, &yes));
+    // One recorded conv / linear forward, with or without a max-pool folded in behind it (pk > 1).  Negotiates the
+    // layouts at both ends with the library: a conv whose kernel reads re-biased bytes asks its producer for them, and
+    // stores re-biased itself when its consumer asked and its kernel can (i8ie_layer_rebiased_io).
+    auto run = [handle, s_in, zp_in, zp_out, m, spatial, oshp, obytes](Tensor<u8_t>& src, int h, int w, bool relu, int border, bool s8,
+                                                                        int pk, int ps) -> std::shared_ptr<Storage> {
+      int out_layout = I8IE_LAYOUT_NCHW, pad = 0;
+      if (spatial) {
         check(i8ie_layer_preferred_layout(handle.get(), &out_layout));
-        if (!yes || out_layout != I8IE_LAYOUT_NHWC) return nullptr;
         check(i8ie_layer_padding(handle.get(), &pad));
-        const std::vector<ssize_t> pshp = {oshp[0], oshp[1], (oshp[2] - pk) / ps + 1, (oshp[3] - pk) / ps + 1};
-        if (srcp.pend && srcp.qsrc && !srcp.pend_relu) {
-          int f32ok = 0;
-          check(i8ie_layer_accepts_f32_input(handle.get(), h, w, &f32ok));
-          if (f32ok) {  // quantize + conv + relu + max-pool in one contraction launch, reading the FP32 input
-            auto st = nhwc_storage(pshp, border, zp_out);
-            check(i8ie_layer_forward_f32_input_pool(handle.get(), (const float*)srcp.qsrc->device_ptr(), m, h, w, srcp.qscale,
-                                                    srcp.qzp, relu ? 1 : 0, pk, ps, (uint8_t*)st->dev, border, nullptr));
-            return st;
-          }
+      }
+      const bool pool = pk > 1;
+      if (pool && out_layout != I8IE_LAYOUT_NHWC) return nullptr;  // (the caller pools the unfused result)
+      std::vector<ssize_t> rshp = oshp;
+      if (pool) {
+        rshp[2] = (oshp[2] - pk) / ps + 1;
+        rshp[3] = (oshp[3] - pk) / ps + 1;
+      }
+      int reads = 0, stores = 0;
+      if (spatial && out_layout == I8IE_LAYOUT_NHWC) check(i8ie_layer_rebiased_io(handle.get(), m, h, w, pool ? pk : 0, ps, &reads, &stores));
+      const bool st_s8 = s8 && stores;
+      if (spatial && out_layout == I8IE_LAYOUT_NHWC && src.pend && src.qsrc && !src.pend_relu) {
+        int yes = 0;
+        check(i8ie_layer_accepts_f32_input(handle.get(), h, w, &yes));
+        if (yes) {  // quantize + conv (+ relu) (+ max-pool) in one kernel, reading the FP32 input
+          auto st = nhwc_storage(rshp, border, zp_out, st_s8);
+          check(i8ie_layer_forward_f32_input_pool(handle.get(), (const float*)src.qsrc->device_ptr(), m, h, w, src.qscale, src.qzp,
+                                                  relu ? 1 : 0, pool ? pk : 0, ps, (uint8_t*)st->dev,
+                                                  st_s8 ? I8IE_LAYOUT_NHWC_S8 : I8IE_LAYOUT_NHWC, border, nullptr));
+          return st;
         }
-        srcp.realize(pad);
-        const uint8_t* ip = srcp.dptr_any();
-        auto st = nhwc_storage(pshp, border, zp_out);
-        check(i8ie_layer_forward_pool(handle.get(), ip, srcp.st->layout, srcp.st->border, m, h, w, s_in, zp_in, relu ? 1 : 0,
-                                      pk, ps, (uint8_t*)st->dev, I8IE_LAYOUT_NHWC, border, nullptr));
-        return st;
+      }
+      const uint8_t* ip;
+      if (spatial) {
+        // ask a still-pending producer for a zero-point border that covers this conv's padding (and for re-biased bytes
+        // when this layer's kernel reads them as they are)
+        src.realize(out_layout == I8IE_LAYOUT_NHWC ? pad : 0, reads != 0);
+        ip = (src.st && src.st->s8 && reads) ? src.dptr_raw() : src.dptr_any();
+      } else {
+        src.realize(0);
+        Storage* s = src.st.get();
+        // x.reshape(n, -1) of an NHWC activation: the Linear layer walks K in (h, w, c) order instead
+        if (s && s->layout == I8IE_LAYOUT_NHWC && s->border == 0 && s->dn == m && s->dh * s->dw > 1 &&
+            (ssize_t)s->dn * s->dc * s->dh * s->dw == src.size) {
+          ip = src.dptr_any();
+          h = s->dh;
+          w = s->dw;
+        } else {
+          ip = src.dptr();
+        }
+      }
+      const int in_layout = src.st->s8 ? I8IE_LAYOUT_NHWC_S8 : src.st->layout, in_border = src.st->border;
+      const int ob = out_layout == I8IE_LAYOUT_NHWC ? border : 0;
+      auto st = out_layout == I8IE_LAYOUT_NHWC ? nhwc_storage(rshp, ob, zp_out, st_s8) : device_storage(obytes);
+      const int ol = st_s8 ? I8IE_LAYOUT_NHWC_S8 : out_layout;
+      if (pool)
+        check(i8ie_layer_forward_pool(handle.get(), ip, in_layout, in_border, m, h, w, s_in, zp_in, relu ? 1 : 0, pk, ps,
+                                      (uint8_t*)st->dev, ol, ob, nullptr));
+      else
+        check(i8ie_layer_forward_fused(handle.get(), ip, in_layout, in_border, m, h, w, s_in, zp_in, relu ? 1 : 0,
+                                       (uint8_t*)st->dev, ol, ob, nullptr));
+      // (the input is released when the last tensor holding this closure lets go of it: right after the
+      // launch in `x = relu(layer(x))`, later if the un-fused result is observed as well)
+      return st;
+    };
+    out.pend = make_pend([run, src, h, w](bool relu, int border, bool s8) mutable { return run(src, h, w, relu, border, s8, 0, 0); });
+    if (spatial) {
+      // max_pool2d right behind this (relu'd) conv: one call of the library, which folds the pool into the convolution's
+      // epilogue where a kernel of its can and runs the max-pool kernel behind it otherwise
+      Tensor<u8_t> srcp = in;
+      out.pend->fn_pool = [run, srcp, h, w](bool relu, int border, bool s8, int pk, int ps) mutable {
+        return run(srcp, h, w, relu, border, s8, pk, ps);
       };
     }
     if (!spatial && out.shape.size() == 2 && out.shape[1] <= 16) {

@@ -322,9 +322,11 @@ class Ctx:
         return r
 
     def layer_forward_pool(self, q_in_nchw, qw, qb, s_in, zp_in, s_w, s_out, zp_out, stride=1, pad=0, in_nhwc=False,
-                           out_nhwc=False, relu=False, in_border=0, out_border=0, pool=None, variant=0):
+                           out_nhwc=False, relu=False, in_border=0, out_border=0, pool=None, variant=0, in_s8=False,
+                           out_s8=False, names=None):
         """i8ie_layer_forward_pool (pool=(k, s)) or i8ie_layer_forward_fused (pool=None) of a conv layer.
-        Returns (out NCHW, acc [n, oh*ow, kc])."""
+        in_s8 / out_s8: the NHWC input / output in the re-biased form (I8IE_LAYOUT_NHWC_S8: every byte ^ 0x80, borders
+        included).  names: list that receives the kernels that ran.  Returns (out NCHW, acc [n, oh*ow, kc])."""
         q_in = np.ascontiguousarray(q_in_nchw, np.uint8)
         qw = np.ascontiguousarray(qw, np.int8)
         qb = np.ascontiguousarray(qb, np.int8)
@@ -336,26 +338,45 @@ class Ctx:
         ck(lib().i8ie_conv2d_create(self.h, qw.ctypes.data_as(C.c_void_p), qb.ctypes.data_as(C.c_void_p), kc, c, kh, kw,
                                     stride, pad, C.c_float(s_w), C.byref(L)))
         ck(lib().i8ie_layer_set_output_qparams(L, C.c_float(s_out), C.c_uint8(zp_out)))
+        assert not (in_s8 and not in_nhwc) and not (out_s8 and not out_nhwc)
         phys_in = self.to_phys(q_in, in_border, zp_in) if in_nhwc else q_in
+        if in_s8:
+            phys_in = phys_in ^ np.uint8(0x80)
         di = self.put(phys_in)
         oshape = (m, ph + 2 * out_border, pw + 2 * out_border, kc) if out_nhwc else (m, kc, ph, pw)
         out = self.empty(oshape, np.uint8)
         acc = self.empty((m, oh * ow, kc), np.int32)
+        ozp = zp_out ^ (0x80 if out_s8 else 0)
         if out_nhwc and out_border:
-            ck(lib().i8ie_fill_border_u8(self.h, out.ptr, m, kc, ph, pw, out_border, C.c_uint8(zp_out)))
+            ck(lib().i8ie_fill_border_u8(self.h, out.ptr, m, kc, ph, pw, out_border, C.c_uint8(ozp)))
+        il = (2 if in_s8 else 1) if in_nhwc else 0
+        ol = (2 if out_s8 else 1) if out_nhwc else 0
+
+        class _Entry(C.Structure):
+            _fields_ = [("name", C.c_char * 64), ("launches", C.c_uint64), ("total_ms", C.c_double),
+                        ("total_ops", C.c_double), ("total_bytes", C.c_double)]
         ck(lib().i8ie_ctx_set_option(self.h, 2, variant))
+        if names is not None:
+            ck(lib().i8ie_profile_start(self.h, 0))
         try:
             if pool is None:
-                ck(lib().i8ie_layer_forward_fused(L, di.ptr, 1 if in_nhwc else 0, in_border, m, h, w, C.c_float(s_in),
-                                                  C.c_uint8(zp_in), 1 if relu else 0, out.ptr, 1 if out_nhwc else 0,
+                ck(lib().i8ie_layer_forward_fused(L, di.ptr, il, in_border, m, h, w, C.c_float(s_in),
+                                                  C.c_uint8(zp_in), 1 if relu else 0, out.ptr, ol,
                                                   out_border, acc.ptr))
             else:
-                ck(lib().i8ie_layer_forward_pool(L, di.ptr, 1 if in_nhwc else 0, in_border, m, h, w, C.c_float(s_in),
+                ck(lib().i8ie_layer_forward_pool(L, di.ptr, il, in_border, m, h, w, C.c_float(s_in),
                                                  C.c_uint8(zp_in), 1 if relu else 0, pool[0], pool[1], out.ptr,
-                                                 1 if out_nhwc else 0, out_border, acc.ptr))
+                                                 ol, out_border, acc.ptr))
         finally:
             ck(lib().i8ie_ctx_set_option(self.h, 2, 0))
+            if names is not None:
+                ents = (_Entry * 64)()
+                cnt = C.c_int(0)
+                ck(lib().i8ie_profile_stop(self.h, ents, 64, C.byref(cnt)))
+                names.extend(ents[i].name.decode().split("|")[0] for i in range(cnt.value))
         phys = out.get()
+        if out_s8:
+            phys = phys ^ np.uint8(0x80)
         o = phys
         if out_nhwc:
             b = out_border

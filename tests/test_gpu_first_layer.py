@@ -51,7 +51,7 @@ def run_first(gpu, x, qw, qb, stride, pad, q_scale, q_zp, s_w, s_out, zp_out, re
                                                     1 if relu else 0, out.ptr, ob, acc.ptr))
         else:
             abi.ck(lib.i8ie_layer_forward_f32_input_pool(L, dx.ptr, n, h, w, C.c_float(q_scale), C.c_uint8(q_zp),
-                                                         1 if relu else 0, pool[0], pool[1], out.ptr, ob, acc.ptr))
+                                                         1 if relu else 0, pool[0], pool[1], out.ptr, 1, ob, acc.ptr))
     finally:
         ents = (_Entry * 64)()
         cnt = C.c_int(0)

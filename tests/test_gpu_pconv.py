@@ -129,3 +129,63 @@ def test_pconv_extreme_operands(gpu, orc, VARIANT):
         abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
     assert np.array_equal(acc, want_acc)
     assert np.array_equal(out, want)
+
+
+# ---- max-pool folded into the epilogue, re-biased (I8IE_LAYOUT_NHWC_S8) input and output ---------------------------------
+POOL_GEOMS = [
+    (270, 384, 13, 13, 256, 3, 1, 1),   # AlexNet conv5: whole 13 x 13 images per tile, pool 3/2 -> 6 x 6
+    (300, 96, 27, 27, 256, 5, 1, 2),    # AlexNet conv2: bands of 9 rows, three per image in one block, windows across bands
+    (260, 64, 14, 14, 192, 3, 1, 1),    # one pass of 192 (odd feature tile count per wave)
+    (257, 256, 13, 13, 384, 3, 1, 1),   # N = 384: one pass of 384
+    (70, 32, 20, 20, 256, 3, 1, 1),     # 20 x 20: bands of 12 and 8 rows
+    (300, 32, 31, 31, 256, 3, 2, 1),    # stride 2: 16 x 16 outputs
+]
+
+
+@pytest.mark.parametrize("geom", POOL_GEOMS)
+@pytest.mark.parametrize("pool", [(3, 2), (2, 2), (3, 1)])
+def test_pconv_folds_the_max_pool(gpu, orc, geom, pool):
+    """conv -> relu -> max_pool2d as one launch of the patch-stationary kernel: the pooled bytes are those of
+    orc.max_pool2d(orc.relu(conv)), the accumulators those of the convolution (unpooled), for windows inside a band
+    and across bands; with a bordered result and with re-biased bytes at either end."""
+    n, c, h, w, kc, k, stride, pad = geom
+    cs = synth.conv_case(orc, 777 + sum(geom), n, c, h, w, kc, k, stride, pad)
+    ref = orc.max_pool2d(orc.relu(cs["out"], cs["zp_out"]), pool[0], pool[1])
+    for in_s8, out_s8, ob in ((False, False, 1), (True, True, 2), (False, True, 0)):
+        names = []
+        out, acc = gpu.layer_forward_pool(cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"], cs["s_out"],
+                                          cs["zp_out"], stride=stride, pad=pad, in_nhwc=True, out_nhwc=True, relu=True,
+                                          in_border=pad, out_border=ob, pool=pool, variant=50, in_s8=in_s8, out_s8=out_s8,
+                                          names=names)
+        assert any(nm.startswith("pconv_pool") for nm in names) and not any(nm.startswith("maxpool") for nm in names), names
+        assert np.array_equal(acc, cs["acc"])
+        assert np.array_equal(out, ref), (in_s8, out_s8, ob)
+
+
+@pytest.mark.parametrize("geom", POOL_GEOMS[:3])
+def test_pconv_rebiased_layouts_without_pool(gpu, orc, geom):
+    n, c, h, w, kc, k, stride, pad = geom
+    cs = synth.conv_case(orc, 778 + sum(geom), n, c, h, w, kc, k, stride, pad)
+    for in_s8, out_s8, relu, ob in ((True, False, False, 0), (False, True, True, 1), (True, True, True, 2)):
+        names = []
+        out, acc = gpu.layer_forward_pool(cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"], cs["s_out"],
+                                          cs["zp_out"], stride=stride, pad=pad, in_nhwc=True, out_nhwc=True, relu=relu,
+                                          in_border=pad, out_border=ob, variant=50, in_s8=in_s8, out_s8=out_s8, names=names)
+        assert any(nm.startswith("pconv") for nm in names) and "rebias_u8" not in names, names
+        assert np.array_equal(acc, cs["acc"])
+        assert np.array_equal(out, orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"])
+
+
+def test_pool_and_rebiased_layouts_where_no_kernel_folds_them(gpu, orc):
+    """The same calls on launches the patch-stationary kernel declines (a handful of images: the tiled kernel runs) and on
+    the any-geometry path: the library pools / re-biases around the kernel, same bytes."""
+    n, c, h, w, kc, k, stride, pad = 3, 32, 13, 13, 64, 3, 1, 1
+    cs = synth.conv_case(orc, 5150, n, c, h, w, kc, k, stride, pad)
+    ref = orc.max_pool2d(orc.relu(cs["out"], cs["zp_out"]), 3, 2)
+    for in_s8, out_s8, ob in ((False, False, 0), (True, True, 1), (True, False, 1), (False, True, 0)):
+        names = []
+        out, acc = gpu.layer_forward_pool(cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"], cs["s_out"],
+                                          cs["zp_out"], stride=stride, pad=pad, in_nhwc=True, out_nhwc=True, relu=True,
+                                          in_border=pad, out_border=ob, pool=(3, 2), in_s8=in_s8, out_s8=out_s8, names=names)
+        assert not any(nm.startswith("pconv") for nm in names), names
+        assert np.array_equal(acc, cs["acc"]) and np.array_equal(out, ref), (in_s8, out_s8, ob)

@@ -39,11 +39,11 @@ def main():
     for variant in (0, 11, 0, 11):
         abi.ck(lib.i8ie_ctx_set_option(g.h, 2, variant))
         for _ in range(3):
-            abi.ck(lib.i8ie_layer_forward_f32_input_pool(L, dx.ptr, n, h, w, C.c_float(0.025), C.c_uint8(127), 1, 3, 2, out.ptr, 2, None))
+            abi.ck(lib.i8ie_layer_forward_f32_input_pool(L, dx.ptr, n, h, w, C.c_float(0.025), C.c_uint8(127), 1, 3, 2, out.ptr, 1, 2, None))
         g.sync()
         abi.ck(lib.i8ie_profile_start(g.h, 0))
         for _ in range(iters):
-            abi.ck(lib.i8ie_layer_forward_f32_input_pool(L, dx.ptr, n, h, w, C.c_float(0.025), C.c_uint8(127), 1, 3, 2, out.ptr, 2, None))
+            abi.ck(lib.i8ie_layer_forward_f32_input_pool(L, dx.ptr, n, h, w, C.c_float(0.025), C.c_uint8(127), 1, 3, 2, out.ptr, 1, 2, None))
         ents = (Entry * 64)()
         cnt = C.c_int(0)
         abi.ck(lib.i8ie_profile_stop(g.h, ents, 64, C.byref(cnt)))
