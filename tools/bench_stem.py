@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """First stage of AlexNet (FP32 input -> quantize -> conv1 -> relu -> max-pool 3/2) through the C-ABI, per-kernel device
-times from the profile hooks: the one-launch form (csrc/i8ie_stem.hip, variant 0) against the older chain
+times from the profile hooks: the first-stage kernel (csrc/i8ie_stem.hip, variant 0) against the older chain
 (quantize + repack, conv_smallc, max-pool; variant 11).  usage: python tools/bench_stem.py [iters] [n]"""
 import ctypes as C
 import os
