@@ -70,3 +70,11 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 // operands through LDS stages.  Takes the amode-0 fields of the call (ksplit / partial unused).
 bool i8ie_flin_wants(int m, int n, int Kpad, bool force);
 int i8ie_flin_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
+
+#if defined(I8IE_DIAG)
+// tools/diag/csrc/i8ie_lgemm.hip (diagnostic build, variant 82): Linear for many rows (m > 256): 64 x 128 block tiles, weights
+// straight from L2 in fragment order, activations register-staged through LDS.  Round 3: 57 + 30 us for fc6 + fc7 at 1000
+// rows on their own (tiled kernel: 65 + 34), 98.5 us inside the AlexNet step (tiled: 99.5): not worth 72 MB of packed weights.
+bool i8ie_lgemm_wants(int m, int n, int K, int Kpad);
+int i8ie_lgemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool perm_panel);
+#endif

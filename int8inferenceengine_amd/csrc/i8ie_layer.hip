@@ -614,7 +614,13 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
     const long tiles_m = (m + 127) / 128, blocks_est = tiles_m * ((L->n + 63) / 64);
     const int nk = L->Kpad / 128;
     int ksplit = 1;
-    if (blocks_est < 256 && nk >= 4 && !flin) {
+#if defined(I8IE_DIAG)
+    const bool lgemm = !need_pad && ctx->variant == 82 && i8ie_lgemm_wants(m, L->n, L->K, L->Kpad) && aligned16(out) &&
+                       (size_t)m * L->K < i8ie_igemm_chunk_limit();
+#else
+    const bool lgemm = false;
+#endif
+    if (blocks_est < 256 && nk >= 4 && !flin && !lgemm) {
       ksplit = (int)((512 + blocks_est - 1) / blocks_est);
       if (ksplit > 8) ksplit = 8;
       if (ksplit > nk / 2) ksplit = nk / 2;
@@ -640,6 +646,12 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
     c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
     c.out = out; c.ob = 0; c.acc = acc; c.Ktrue = L->K;
     if (flin) return i8ie_flin_launch(ctx, c);
+#if defined(I8IE_DIAG)
+    if (lgemm) {  // (experiment: tools/diag/csrc/i8ie_lgemm.hip)
+      c.wcache = &L->wc;
+      return i8ie_lgemm_launch(ctx, c, panel == L->Bperm && L->Bperm != nullptr);
+    }
+#endif
     return i8ie_igemm_launch(ctx, c);
   }
 

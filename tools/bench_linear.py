@@ -44,6 +44,16 @@ def main():
                     g.sync()
                     res.setdefault(v, []).append((time.perf_counter() - t0) / iters * 1e6)
             print(name, "m=%d" % m, " ".join("v%d: %.1f us" % (v, min(t)) for v, t in res.items()), flush=True)
+            # per-kernel device time (profile hooks) of the default dispatch
+            class _E(C.Structure):
+                _fields_ = [("name", C.c_char * 64), ("launches", C.c_uint64), ("total_ms", C.c_double), ("total_ops", C.c_double), ("total_bytes", C.c_double)]
+            abi.ck(lib.i8ie_ctx_set_option(g.h, 2, 0))
+            abi.ck(lib.i8ie_profile_start(g.h, 0))
+            for _ in range(iters):
+                abi.ck(lib.i8ie_layer_forward_fused(L, di.ptr, 0, 0, m, 0, 0, C.c_float(0.025), C.c_uint8(127), 1, out.ptr, 0, 0, None))
+            ents = (_E * 64)(); cnt = C.c_int(0)
+            abi.ck(lib.i8ie_profile_stop(g.h, ents, 64, C.byref(cnt)))
+            print("    " + " | ".join("%s %.1f us (%.0f TOPS)" % (ents[i].name.decode().split("|")[0], ents[i].total_ms / ents[i].launches * 1e3, ents[i].total_ops / (ents[i].total_ms * 1e-3) / 1e12) for i in range(cnt.value)), flush=True)
             di.free()
         lib.i8ie_layer_destroy(L)
 
