@@ -231,6 +231,20 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     e.lom = __builtin_amdgcn_readfirstlane(b.z); e.jm = __builtin_amdgcn_readfirstlane(b.w);
     return e;
   };
+  // patch of strip t of image im -> patch buffer pb: one contiguous run of the s2d image, whole 1 KiB LDS-DMA pieces, dealt
+  // to the four waves of a role (w4 = wave & 3).  The MULTIPLYING waves issue them (first thing in an interval, for the
+  // strip after the one they are about to multiply; awaited before the interval's barrier): they have the slack -- the
+  // vector waves are the kernel's critical path, and three pieces cost a wave ~700 cycles of issue (phase stamps)
+  auto patch_dma = [&](int im, int t, int pb) {
+    const StemStrip e = strip(t);
+    if (e.pbytes <= 0) return;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(p.img + (size_t)im * p.img_pitch + (unsigned)e.poff), 0, e.pbytes, 0x00020000);
+    const int pieces = (e.pbytes + 1023) >> 10;  // the last piece reads zeros past the run (bounds-checked descriptor)
+    uint8_t* dst = smem + p.lds_patch + pb * p.patchB;
+    for (int q = wave & 3; q < pieces; q += 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, (q * 64 + lane) * 16, 0, 0, 0);
+  };
 #if defined(I8IE_DIAG)
   unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
   auto stamp = [&](int i) {
@@ -279,12 +293,26 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     if (lx < 0) { lx += p.OW; --lr; } else if (lx >= p.OW) { lx -= p.OW; ++lr; }
     const int aoff = (lr * p.sq * p.WX + lx * p.sq) * 48;
     const int roff = lx * p.pitchP + 16 * hh;
-    STEM_BAR();  // (the first patch: requested and awaited by the vector waves)
+    int t = 0, ib = 0, pbuf = 0;  // strip inside the image; (i * OH) % RING; patch buffer g & 1
+    int tn = 0, imn = (int)blockIdx.x;  // the strip whose patch is requested next (one ahead of t)
+    auto next_n = [&]() {
+      if (++tn == T) {
+        tn = 0;
+        imn += (int)gridDim.x;
+      }
+    };
+    patch_dma(imn, tn, 0);
+    next_n();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STEM_BAR();  // (the first patch)
 #if defined(I8IE_DIAG)
     if (p.dbg) tq = __builtin_amdgcn_s_memtime();
 #endif
-    int t = 0, ib = 0, pbuf = 0;  // strip inside the image; (i * OH) % RING; patch buffer g & 1
     for (int g = 0; g < G; ++g) {
+      if (g + 1 < G) {  // the patch of strip g + 1 -> the other buffer (strip g - 1 was its last reader)
+        patch_dma(imn, tn, pbuf ^ 1);
+        next_n();
+      }
       const StemStrip e = strip(t);
       const int npx = (e.hi - e.lo) * p.OW;
       if (wave * 32 < npx) {  // (wave-uniform: a short strip leaves the upper tiles without work)
@@ -330,9 +358,11 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
           });
         }
         {
-          v4i ring[DEPTH], bring[DEPTH];
+          // (one MFMA per k-step here: 32 cycles a step, an LDS round trip is 150-200 under load -- the reads run six ahead)
+          constexpr int DB = KS < 6 ? KS : 6;
+          v4i ring[DB], bring[DB];
           const uint8_t* const bbase = smem + p.lds_bfrag + lane * 16;
-          static_for<0, DEPTH>([&](auto jc) {
+          static_for<0, DB>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             ring[j] = *reinterpret_cast<const v4i*>(abase + koff[j]);
             bring[j] = *reinterpret_cast<const v4i*>(bbase + j * 1024);
@@ -340,10 +370,10 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
           __builtin_amdgcn_sched_barrier(0);
           static_for<0, KS>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            const v4i af = ring[j % DEPTH], bf = bring[j % DEPTH];
-            if constexpr (j + DEPTH < KS) {
-              ring[j % DEPTH] = *reinterpret_cast<const v4i*>(abase + koff[j + DEPTH]);
-              bring[j % DEPTH] = *reinterpret_cast<const v4i*>(bbase + (j + DEPTH) * 1024);
+            const v4i af = ring[j % DB], bf = bring[j % DB];
+            if constexpr (j + DB < KS) {
+              ring[j % DB] = *reinterpret_cast<const v4i*>(abase + koff[j + DB]);
+              bring[j % DB] = *reinterpret_cast<const v4i*>(bbase + (j + DB) * 1024);
               __builtin_amdgcn_sched_barrier(0);
             }
             acc[NG - 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf, af, j == 0 ? z : acc[NG - 1], 0, 0, 0);
@@ -365,6 +395,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         stamp(1);  // ring writes
 #endif
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patch requested at the top of the interval has landed
       STEM_BAR();
       stamp(2);  // at the barrier
       if (++t == T) {
@@ -407,20 +438,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   const int nqo = N4 >> 3, npo = (p.PW + 7) >> 3, ntask = nqo * npo;
   const int rd_lane = pl * p.ps * p.pitchP + ql * 16;  // LDS byte offset of this lane's window origin inside a task
   const int st_lane = pl * p.N + ql * 4;               // output byte offset of this lane inside a task
-  int vm_stores = 0;  // output stores this wave has issued in the current interval (wave-uniform)
 
-  // patch of strip t of image im -> patch buffer pb: one contiguous run of the s2d image, whole 1 KiB pieces
-  auto patch_dma = [&](int im, int t, int pb) {
-    const StemStrip e = strip(t);
-    if (e.pbytes <= 0) return;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(p.img + (size_t)im * p.img_pitch + (unsigned)e.poff), 0, e.pbytes, 0x00020000);
-    const int pieces = (e.pbytes + 1023) >> 10;  // the last piece reads zeros past the run (bounds-checked descriptor)
-    uint8_t* dst = smem + p.lds_patch + pb * p.patchB;
-    for (int q = vwave; q < pieces; q += 4) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, (q * 64 + lane) * 16, 0, 0, 0);
-    }
-  };
   // A wave's pool tasks: k = vwave + 4 u (+ 12 per further round); task k = (pixel octet po, quad octet qo).  What does
   // not depend on the pooled row is worked out once: LDS offset of the lane's window origin, output offset (lanes past
   // the row's last pixel: read pixel 0 of the task, store beyond the descriptor's range), LDS address of its oc' quad
@@ -508,7 +526,6 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         for (int u = 0; u < UN; ++u) {
           if (u < nu) {
             __builtin_amdgcn_raw_buffer_store_b32(d[u] ^ p.xor_out, rsO, tk[u].st, orow, 0);
-            ++vm_stores;
           }
         }
         stamp(5);  // (pool pass: maxima, requantiser, stores)
@@ -559,33 +576,15 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     }
   };
 
-  // running state: strip g + 1 (the patch to request), strip g - 1 (the rows to pool): image, strip, ring base
-  int t2 = 0, im2 = (int)blockIdx.x, pb2 = 0;
+  // running state: strip g - 1 (the rows to pool): image, strip, ring base
   int t1 = 0, im1 = (int)blockIdx.x, ib1 = 0;
-  auto next2 = [&]() {
-    if (++t2 == T) {
-      t2 = 0;
-      im2 += (int)gridDim.x;
-    }
-    pb2 ^= 1;
-  };
-  patch_dma(im2, t2, pb2);
-  next2();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STEM_BAR();
 #if defined(I8IE_DIAG)
   if (p.dbg) tq = __builtin_amdgcn_s_memtime();
 #endif
   for (int g = 0; g <= G; ++g) {
-    // interval g: the multiplying waves work on strip g (none at g == G) in patch buffer g & 1; here: request the patch of
-    // strip g + 1 into the other buffer (strip g - 1 was its last reader), then the pooled rows completed by strip g - 1.
-    // Before the barrier that request has to have landed; vector-memory operations retire in issue order and it was this
-    // wave's first of the interval, so the output stores issued behind it may stay in flight.
-    vm_stores = 0;
-    if (g + 1 < G) {
-      patch_dma(im2, t2, pb2);
-      next2();
-    }
+    // interval g: the multiplying waves work on strip g (none at g == G); here: the pooled rows completed by strip g - 1.
+    // The output stores stay in flight across the barriers (STEM_BAR waits for LDS operations only).
     stamp(0);  // patch request
     if (g >= 1) {
       const StemStrip e = strip(t1);
@@ -605,8 +604,8 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
       }
     }
     stamp(1);  // pool pass
-    if constexpr (ACC) wait_vm_keep(0); else wait_vm_keep(vm_stores);
-    stamp(2);  // waiting for the patch requested at the start of the interval
+    if constexpr (ACC) wait_vm_keep(0);
+    stamp(2);
     STEM_BAR();
     stamp(3);  // at the barrier
   }
