@@ -287,7 +287,7 @@ def main():
     # serialises every dispatch) and committed with the commit they were taken at; used only when they describe
     # this kernel at this workload, otherwise null
     traffic, traffic_meta = None, None
-    for cand in ("r02_traffic.json", "r01_traffic.json"):
+    for cand in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
             if tj.get("kernel") == dom and n_total == 1000 and world == 1 and name == "alexnet":
