@@ -64,6 +64,7 @@ int i8ie_sync(i8ie_ctx* ctx);
 #define I8IE_VARIANT_IGEMM_REGSTAGE 3  /* tiled contraction kernel, one LDS stage filled through registers (Linear's default) */
 #define I8IE_VARIANT_IGEMM_DMA 5       /* tiled contraction kernel, one LDS stage filled by LDS-DMA (the tiled conv default) */
 #define I8IE_VARIANT_TILED 11          /* tiled contraction kernel everywhere: no patch-stationary conv, split-K Linear, dot4 head */
+#define I8IE_VARIANT_STEM_WHOLE 12     /* first-stage kernel (csrc/i8ie_stem.hip): whole images per block at any batch size (no parts) */
 #define I8IE_VARIANT_PCONV 50          /* patch-stationary conv kernel (csrc/i8ie_pconv.hip) at any batch size */
 #define I8IE_VARIANT_PCONV_2PASS 54    /* the same, N = 384 as two passes of 192 and no 128-wide pass split */
 #define I8IE_VARIANT_TCONV 70          /* two-team patch-stationary conv kernel (csrc/i8ie_tconv.hip) wherever its shape rules allow */

@@ -145,7 +145,9 @@ struct StemArgs {
   int WX, rowB;        // s2d pixels per row; bytes per s2d row
   int OH, OW, sq;      // conv output dims; stride / 4
   int KC4, RC, nch;    // s2d rows a window spans; 16-byte chunks per run (3 x s2d pixels per run); chunks in all
-  int NR, first, T;    // conv rows per strip; rows of an image's first strip; strips per image
+  int NR, first, T;    // conv rows per strip; rows of a part's first strip; strips per part (the longest part's count)
+  int parts, lg_parts; // an image is cut into 2^lg_parts parts of whole pooled rows, each a unit of its own (small batches:
+                       // more units than CUs); a part recomputes the pk - ps conv rows it shares with the part above it
   int pk, ps, PH, PW;  // pool window / stride (1, 1 = no pool), output dims after the pool
   const int8_t* B;     // [N][Kpad] K ordered (s2d row, s2d px, row-in-4, px-in-4, ch), zero padded
   int Kpad, N;
@@ -158,7 +160,7 @@ struct StemArgs {
   int32_t* acc;      // ACC kernels: [n * OH * OW][N] pre-requant accumulators of the convolution
   int pitchP, ringRowB, RING;           // INT32 ring: bytes per pixel (4 N + 16), per conv row, rows
   int patchB;                            // bytes of a patch buffer (whole 1 KiB pieces)
-  int lds_patch, lds_ring, lds_ocp, lds_tab, lds_dump, lds_bfrag;  // LDS offsets (lds_dump: 2 KiB that lanes past a strip's last pixel store into; lds_bfrag: the last feature group's weights)
+  int lds_patch, lds_ring, lds_ocp, lds_tab, lds_adv, lds_dump, lds_bfrag;  // LDS offsets (lds_dump: 2 KiB that lanes past a strip's last pixel store into; lds_bfrag: the last feature group's weights)
   unsigned out_bytes;
   float rcpOW;
   unsigned long long* dbg;   // diagnostic build ($I8IE_STEM_STAMPS): per block and wave, cycles per phase; null otherwise
@@ -186,11 +188,14 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, l31 = lane & 31;
 
-  // images of this block: b, b + gridDim.x, ...; its strips are walked as one sequence g = 0 .. G - 1 (image-major)
-  const int n_mine = ((int)blockIdx.x < p.n_img) ? (p.n_img - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  // units (image, part) of this block: b, b + gridDim.x, ...; their strips are walked as one sequence g = 0 .. G - 1.
+  // Conv rows are numbered through that sequence for the ring: row r of a part that starts at row R0 sits in slot
+  // (ib + r - R0) % RING, ib = the rows of all earlier units of the block, mod RING.
+  const int n_units = p.n_img << p.lg_parts;
+  const int n_mine = ((int)blockIdx.x < n_units) ? (n_units - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   if (n_mine == 0) return;
   const int T = p.T, G = n_mine * T, RING = p.RING;
-  const int ohm = p.OH % RING;  // conv row r of the block's i-th image sits in ring slot (i * OH + r) % RING
+  const int pmask = p.parts - 1;
 
   for (int i = tid; i < p.N; i += 512) reinterpret_cast<int*>(smem + p.lds_ocp)[i] = p.ocp[i];
   // weights of the LAST feature group, in MFMA fragment order [k-step][lane][16 B]: the multiplying waves read them from
@@ -201,29 +206,40 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     *reinterpret_cast<v4i*>(smem + p.lds_bfrag + i * 16) =
         *reinterpret_cast<const v4i*>(p.B + (size_t)((NG - 1) * 32 + (ln & 31)) * p.Kpad + j * 32 + (ln >> 5) * 16);
   }
-  if (tid < T) {  // (T <= 256: checked on the host)
-    auto hi_of = [&](int t) { const int v = p.first + t * p.NR; return v < p.OH ? v : p.OH; };
-    auto done = [&](int hi) {
-      if (hi < p.pk) return 0;
-      const int e = (hi - p.pk) / p.ps + 1;
-      return e < p.PH ? e : p.PH;
+  if (tid < T * p.parts) {  // (T * parts <= 256: checked on the host)
+    int part = 0, t = tid;
+    while (t >= T) {
+      t -= T;
+      ++part;
+    }
+    // part = pooled rows [J0, J1) = conv rows [R0, R1); its strips: `first` rows, then NR at a time (empty past the end)
+    const int J0 = part * p.PH / p.parts, J1 = (part + 1) * p.PH / p.parts;
+    const int R0 = J0 * p.ps, R1 = part + 1 == p.parts ? p.OH : (J1 - 1) * p.ps + p.pk;
+    auto hi_of = [&](int tt) { const int v = R0 + p.first + tt * p.NR; return v < R1 ? v : R1; };
+    auto done = [&](int hi) {  // pooled rows of the image whose window ends at or below conv row hi, inside this part
+      if (hi < p.pk) return J0;
+      int e = (hi - p.pk) / p.ps + 1;
+      e = e < J1 ? e : J1;
+      return e > J0 ? e : J0;
     };
     StemStrip e;
-    e.hi = hi_of(tid);
-    e.lo = tid == 0 ? 0 : hi_of(tid - 1);
+    e.hi = hi_of(t);
+    e.lo = t == 0 ? R0 : hi_of(t - 1);
     const int rows = e.hi > e.lo ? (e.hi - e.lo - 1) * p.sq + p.KC4 : 0;
     e.poff = e.lo * p.sq * p.rowB;
     e.pbytes = rows * p.rowB;
     if ((unsigned)(e.poff + e.pbytes) > p.img_pitch) e.pbytes = (int)p.img_pitch - e.poff;  // (never: the image holds every window row)
     e.j1 = done(e.hi);
-    e.j0 = tid == 0 ? 0 : done(e.lo);
-    e.lom = e.lo % RING;
-    e.jm = (e.j0 * p.ps) % RING;
+    e.j0 = t == 0 ? J0 : done(e.lo);
+    e.lom = (e.lo - R0) % RING;
+    e.jm = (e.j0 * p.ps - R0) % RING;
     reinterpret_cast<StemStrip*>(smem + p.lds_tab)[tid] = e;
+    if (t == 0) reinterpret_cast<int*>(smem + p.lds_adv)[part] = (R1 - R0) % RING;
   }
   __syncthreads();  // (every wave, before the roles part: the tables are read from here on)
-  auto strip = [&](int t) {  // (wave-uniform t: the entry lands in SGPRs)
-    const v4i a = *reinterpret_cast<const v4i*>(smem + p.lds_tab + t * 32), b = *reinterpret_cast<const v4i*>(smem + p.lds_tab + t * 32 + 16);
+  auto strip = [&](int unit, int t) {  // (wave-uniform: the entry lands in SGPRs)
+    const int idx = (unit & pmask) * T + t;
+    const v4i a = *reinterpret_cast<const v4i*>(smem + p.lds_tab + idx * 32), b = *reinterpret_cast<const v4i*>(smem + p.lds_tab + idx * 32 + 16);
     StemStrip e;
     e.lo = __builtin_amdgcn_readfirstlane(a.x); e.hi = __builtin_amdgcn_readfirstlane(a.y);
     e.poff = __builtin_amdgcn_readfirstlane(a.z); e.pbytes = __builtin_amdgcn_readfirstlane(a.w);
@@ -235,11 +251,12 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   // to the four waves of a role (w4 = wave & 3).  The MULTIPLYING waves issue them (first thing in an interval, for the
   // strip after the one they are about to multiply; awaited before the interval's barrier): they have the slack -- the
   // vector waves are the kernel's critical path, and three pieces cost a wave ~700 cycles of issue (phase stamps)
-  auto patch_dma = [&](int im, int t, int pb) {
-    const StemStrip e = strip(t);
+  auto adv_of = [&](int unit) { return __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem + p.lds_adv)[unit & pmask]); };
+  auto patch_dma = [&](int unit, int t, int pb) {
+    const StemStrip e = strip(unit, t);
     if (e.pbytes <= 0) return;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t*>(p.img + (size_t)im * p.img_pitch + (unsigned)e.poff), 0, e.pbytes, 0x00020000);
+        const_cast<uint8_t*>(p.img + (size_t)(unit >> p.lg_parts) * p.img_pitch + (unsigned)e.poff), 0, e.pbytes, 0x00020000);
     const int pieces = (e.pbytes + 1023) >> 10;  // the last piece reads zeros past the run (bounds-checked descriptor)
     uint8_t* dst = smem + p.lds_patch + pb * p.patchB;
     for (int q = wave & 3; q < pieces; q += 4)
@@ -293,8 +310,8 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     if (lx < 0) { lx += p.OW; --lr; } else if (lx >= p.OW) { lx -= p.OW; ++lr; }
     const int aoff = (lr * p.sq * p.WX + lx * p.sq) * 48;
     const int roff = lx * p.pitchP + 16 * hh;
-    int t = 0, ib = 0, pbuf = 0;  // strip inside the image; (i * OH) % RING; patch buffer g & 1
-    int tn = 0, imn = (int)blockIdx.x;  // the strip whose patch is requested next (one ahead of t)
+    int t = 0, un = (int)blockIdx.x, ib = 0, pbuf = 0;  // strip inside the unit; the unit; its ring base; patch buffer g & 1
+    int tn = 0, imn = (int)blockIdx.x;  // the strip whose patch is requested next (one ahead of t): strip, unit
     auto next_n = [&]() {
       if (++tn == T) {
         tn = 0;
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         patch_dma(imn, tn, pbuf ^ 1);
         next_n();
       }
-      const StemStrip e = strip(t);
+      const StemStrip e = strip(un, t);
       const int npx = (e.hi - e.lo) * p.OW;
       if (wave * 32 < npx) {  // (wave-uniform: a short strip leaves the upper tiles without work)
         const bool valid = pp < npx;
@@ -400,8 +417,9 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
       stamp(2);  // at the barrier
       if (++t == T) {
         t = 0;
-        ib += ohm;
+        ib += adv_of(un);
         if (ib >= RING) ib -= RING;
+        un += (int)gridDim.x;
       }
       pbuf ^= 1;
     }
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     }
   };
 
-  // running state: strip g - 1 (the rows to pool): image, strip, ring base
+  // running state: strip g - 1 (the rows to pool): strip, unit, ring base
   int t1 = 0, im1 = (int)blockIdx.x, ib1 = 0;
   STEM_BAR();
 #if defined(I8IE_DIAG)
@@ -587,20 +605,21 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     // The output stores stay in flight across the barriers (STEM_BAR waits for LDS operations only).
     stamp(0);  // patch request
     if (g >= 1) {
-      const StemStrip e = strip(t1);
+      const StemStrip e = strip(im1, t1);
+      const int img = im1 >> p.lg_parts;
       if (e.j1 > e.j0) {
-        if (p.pk == 3) pool_rows(std::integral_constant<int, 3>{}, im1, ib1, e);
-        else if (p.pk == 2) pool_rows(std::integral_constant<int, 2>{}, im1, ib1, e);
-        else pool_rows(std::integral_constant<int, 1>{}, im1, ib1, e);
+        if (p.pk == 3) pool_rows(std::integral_constant<int, 3>{}, img, ib1, e);
+        else if (p.pk == 2) pool_rows(std::integral_constant<int, 2>{}, img, ib1, e);
+        else pool_rows(std::integral_constant<int, 1>{}, img, ib1, e);
       }
       if constexpr (ACC) {
-        if (e.hi > e.lo) dump_acc(im1, ib1, e);
+        if (e.hi > e.lo) dump_acc(img, ib1, e);
       }
       if (++t1 == T) {
         t1 = 0;
-        im1 += (int)gridDim.x;
-        ib1 += ohm;
+        ib1 += adv_of(im1);
         if (ib1 >= RING) ib1 -= RING;
+        im1 += (int)gridDim.x;
       }
     }
     stamp(1);  // pool pass
@@ -630,12 +649,12 @@ int launch_stem(i8ie_ctx* ctx, const StemArgs& a, int grid, int lds) {
 }
 
 struct StemPlan {
-  int KC4, KA4, HY, WX, K2, KS, KST, NR, first, T, pk, ps, PH, PW, carry, RING, pitchP, ringRowB, patchB, lds_tab, lds_dump, lds_bfrag, lds;
+  int KC4, KA4, HY, WX, K2, KS, KST, NR, first, T, parts, pk, ps, PH, PW, carry, RING, pitchP, ringRowB, patchB, lds_tab, lds_adv, lds_dump, lds_bfrag, lds;
 };
 
 // geometry this kernel takes: <= 3 channels, stride a multiple of 4, N in {32, 64, 96}, K within 14 k-steps, a strip of
 // whole conv rows within 128 pixels, the INT32 ring and three patches within the CU's LDS
-bool stem_plan(int c, int stride, int N, int KH, int KW, int OH, int OW, int pool_k, int pool_s, StemPlan* out) {
+bool stem_plan(int c, int stride, int N, int KH, int KW, int OH, int OW, int pool_k, int pool_s, int parts, StemPlan* out) {
   if (c > 3 || c < 1 || stride < 4 || stride % 4 != 0) return false;
   if (N % 32 != 0 || N < 32 || N > 96) return false;
   StemPlan s{};
@@ -661,37 +680,57 @@ bool stem_plan(int c, int stride, int N, int KH, int KW, int OH, int OW, int poo
   s.NR = NR;
   s.first = s.carry > 0 ? s.carry : NR;
   if (s.first > OH) s.first = OH;
-  s.T = 1 + (OH > s.first ? (OH - s.first + NR - 1) / NR : 0);
+  if (parts != 1 && parts != 2 && parts != 4) return false;
+  if (s.PH < 2 * parts) return false;  // (at least two pooled rows per part)
+  s.parts = parts;
+  // part q = pooled rows [J0, J1) = conv rows [R0, R1) (the kernel's table, restated)
+  auto J0_of = [&](int q) { return q * s.PH / parts; };
+  auto R0_of = [&](int q) { return J0_of(q) * s.ps; };
+  auto R1_of = [&](int q) { return q + 1 == parts ? OH : (J0_of(q + 1) - 1) * s.ps + s.pk; };
+  s.T = 1;
+  for (int q = 0; q < parts; ++q) {
+    const int rows = R1_of(q) - R0_of(q);
+    const int t = 1 + (rows > s.first ? (rows - s.first + NR - 1) / NR : 0);
+    if (t > s.T) s.T = t;
+  }
   s.RING = 2 * NR + s.carry;
   s.pitchP = N * 4 + 16;
   s.ringRowB = OW * s.pitchP;
   const int prmax = (NR - 1) * sq + s.KC4;
   s.patchB = ((prmax * s.WX * 48 + 1023) & ~1023) + 1024;  // (+ one piece: the pad chunk of the last pixel may read past the run)
-  if (s.T > 256) return false;  // (the strip table is filled by the first 256 threads)
+  if (s.T * parts > 256) return false;  // (the strip table is filled by the first 256 threads)
   s.KST = s.KS <= 6 ? 6 : (s.KS <= 10 ? 10 : kStemMaxKS);  // k-steps of the kernel instantiation
   s.lds_tab = 2 * s.patchB + s.RING * s.ringRowB + N * 4 + 64;
-  s.lds_dump = s.lds_tab + s.T * 32;
+  s.lds_adv = s.lds_tab + s.T * parts * 32;
+  s.lds_dump = s.lds_adv + 16;
   s.lds_bfrag = s.lds_dump + 2048;
   s.lds = s.lds_bfrag + s.KST * 1024;
   if (s.lds > 160 * 1024) return false;
-  // the ring holds every conv row in flight: walk the intervals of two consecutive images (rows numbered through)
-  auto hi_of = [&](int t) { const int v = s.first + t * s.NR; return v < OH ? v : OH; };
-  auto done = [&](int hi) { if (hi < s.pk) return 0; const int e = (hi - s.pk) / s.ps + 1; return e < s.PH ? e : s.PH; };
-  for (int g = 1; g <= 2 * s.T; ++g) {  // interval g: strip g written, pooled rows completed by strip g - 1 read
-    const int i1 = (g - 1) / s.T, t1 = (g - 1) % s.T;
-    const int j0 = done(t1 > 0 ? hi_of(t1 - 1) : 0), j1 = done(hi_of(t1));
-    int lo_read = -1, hi_read = -1;
-    if (j1 > j0) {
-      lo_read = i1 * OH + j0 * s.ps;
-      hi_read = i1 * OH + (j1 - 1) * s.ps + s.pk - 1;
+  // the ring holds every conv row in flight: walk the intervals of two consecutive units (any part after any part; rows
+  // numbered through: unit 2's row r sits rows(unit 1) + r - R0 further on)
+  for (int qa = 0; qa < parts; ++qa)
+    for (int qb = 0; qb < parts; ++qb) {
+      const int q_of[2] = {qa, qb};
+      const int base[2] = {0, R1_of(qa) - R0_of(qa)};
+      auto hi_of = [&](int u, int t) { const int v = R0_of(q_of[u]) + s.first + t * s.NR; return v < R1_of(q_of[u]) ? v : R1_of(q_of[u]); };
+      auto lo_of = [&](int u, int t) { return t == 0 ? R0_of(q_of[u]) : hi_of(u, t - 1); };
+      auto done = [&](int u, int hi) {
+        const int J0 = J0_of(q_of[u]), J1 = q_of[u] + 1 == parts ? s.PH : J0_of(q_of[u] + 1);
+        if (hi < s.pk) return J0;
+        int e = (hi - s.pk) / s.ps + 1;
+        e = e < J1 ? e : J1;
+        return e > J0 ? e : J0;
+      };
+      for (int g = 1; g < 2 * s.T; ++g) {  // interval g: strip g written, pooled rows completed by strip g - 1 read
+        const int u1 = (g - 1) / s.T, t1 = (g - 1) % s.T;
+        const int j0 = t1 == 0 ? J0_of(q_of[u1]) : done(u1, lo_of(u1, t1)), j1 = done(u1, hi_of(u1, t1));
+        if (j1 <= j0) continue;
+        const int lo_read = base[u1] + j0 * s.ps - R0_of(q_of[u1]);
+        const int u2 = g / s.T, t2 = g % s.T;
+        const int wlo = base[u2] + lo_of(u2, t2) - R0_of(q_of[u2]), whi = base[u2] + hi_of(u2, t2) - 1 - R0_of(q_of[u2]);
+        if (whi >= wlo && whi - lo_read + 1 > s.RING) return false;
+      }
     }
-    if (g < 2 * s.T) {
-      const int i2 = g / s.T, t2 = g % s.T;
-      const int wlo = i2 * OH + (t2 > 0 ? hi_of(t2 - 1) : 0), whi = i2 * OH + hi_of(t2) - 1;
-      if (lo_read >= 0 && whi >= wlo && whi - lo_read + 1 > s.RING) return false;
-    }
-    (void)hi_read;
-  }
   *out = s;
   return true;
 }
@@ -700,7 +739,7 @@ bool stem_plan(int c, int stride, int N, int KH, int KW, int OH, int OW, int poo
 
 int i8ie_stem_supported(int c, int stride, int N, int KH, int KW, int OH, int OW, int pool_k, int pool_s) {
   StemPlan s;
-  return stem_plan(c, stride, N, KH, KW, OH, OW, pool_k, pool_s, &s) ? 1 : 0;
+  return stem_plan(c, stride, N, KH, KW, OH, OW, pool_k, pool_s, 1, &s) ? 1 : 0;
 }
 
 // the weight panel's K length (bytes per output feature, a multiple of 32) and the K index of (ch, kh, kw)
@@ -721,8 +760,21 @@ size_t i8ie_stem_scratch_bytes(int n, int KH, int KW, int stride, int OH, int OW
 }
 
 int i8ie_stem_launch(i8ie_ctx* ctx, const I8ieStemCall& c) {
+  static int cus[64] = {};
+  const int dev = ctx->device & 63;
+  if (cus[dev] == 0) {
+    hipDeviceProp_t prop;
+    I8IE_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  // Fewer images than CUs (the shard of a multi-GPU batch): an image is cut into 2 or 4 parts of whole pooled rows, each a
+  // unit of its own; a part recomputes the pk - ps conv rows it shares with its neighbour (1 of 28 on AlexNet's conv1)
   StemPlan s;
-  if (!stem_plan(c.c, c.stride, c.N, c.KH, c.KW, c.OH, c.OW, c.pool_k, c.pool_s, &s)) {
+  int parts = 1;
+  while (parts < 4 && (long)c.n * parts * 4 < (long)cus[dev] * 3) parts *= 2;
+  if (ctx->variant == 12) parts = 1;  // (I8IE_VARIANT_STEM_WHOLE)
+  while (parts > 1 && !stem_plan(c.c, c.stride, c.N, c.KH, c.KW, c.OH, c.OW, c.pool_k, c.pool_s, parts, &s)) parts /= 2;
+  if (!stem_plan(c.c, c.stride, c.N, c.KH, c.KW, c.OH, c.OW, c.pool_k, c.pool_s, parts, &s)) {
     i8ie_set_error("i8ie_stem_launch: geometry not supported");
     return I8IE_ERR_STATE;
   }
@@ -772,15 +824,11 @@ int i8ie_stem_launch(i8ie_ctx* ctx, const I8ieStemCall& c) {
   a.rcpOW = 1.0f / (float)c.OW;
   a.RC = s.KA4 * 3;
   a.nch = s.KC4 * a.RC;
-  static int cus[64] = {};
-  const int dev = ctx->device & 63;
-  if (cus[dev] == 0) {
-    hipDeviceProp_t prop;
-    I8IE_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
-    cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  a.parts = s.parts;
+  a.lg_parts = s.parts == 4 ? 2 : (s.parts == 2 ? 1 : 0);
+  a.lds_adv = s.lds_adv;
   int grid = cus[dev];
-  if (grid > c.n) grid = c.n;
+  if (grid > c.n * s.parts) grid = c.n * s.parts;
   const double ops = 2.0 * c.n * c.OH * c.OW * (double)c.N * c.c * c.KH * c.KW;
   const double bytes = (double)c.n * img_pitch + (double)out_bytes;
   I8ieProfScope prof(ctx, s.pk > 1 ? "stem_conv_pool" : "stem_conv", ops, bytes);
@@ -811,7 +859,7 @@ int i8ie_stem_launch(i8ie_ctx* ctx, const I8ieStemCall& c) {
       for (int w = 4; w < 8; ++w) fprintf(stderr, " w%d %.0f|%.0f,%.0f,%.0f|%.0f|%.0f", w, sm[w][0] / n, sm[w][1] / n, sm[w][4] / n, sm[w][5] / n, sm[w][2] / n, sm[w][3] / n);
       fprintf(stderr, "\n");
     }
-  } report{ctx, a.dbg, grid, c.n * s.T, a.dbg != nullptr};
+  } report{ctx, a.dbg, grid, c.n * s.T * s.parts, a.dbg != nullptr};
 #endif
   const int NG = c.N / 32;
 #define I8IE_STEM_KS(NGV)                                                   \

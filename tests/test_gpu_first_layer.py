@@ -82,14 +82,18 @@ GEOMS = [
     (3, 3, 35, 35, 160, 11, 4, 5),    # 5 feature tiles: beyond the first-stage kernel, the older kernel takes it
     (600, 3, 43, 43, 64, 7, 4, 3),    # more images than CUs: blocks walk two or three images (ring and patch sequence
                                       # run through the image boundary)
+    (100, 3, 43, 43, 64, 7, 4, 3),    # fewer images than CUs: an image is cut into two parts of whole pooled rows, each a
+                                      # unit of its own (the images of n <= 5 above: four parts); variant 12 keeps whole images
 ]
 POOLS = [None, (3, 2), (2, 2)]
 
 
-@pytest.mark.parametrize("variant", [0])
+@pytest.mark.parametrize("variant", [0, 12])
 @pytest.mark.parametrize("geom", GEOMS)
 def test_fused_first_layer_bit_exact(gpu, orc, geom, variant):
     n, c, h, w, kc, k, stride, pad = geom
+    if variant == 12 and n >= 192:
+        pytest.skip("whole images per block anyway")
     abi.ck(abi.lib().i8ie_ctx_set_option(gpu.h, 2, variant))
     rng = np.random.default_rng(sum(geom))
     x = rng.uniform(-2.2, 2.6, (n, c, h, w)).astype(np.float32)
