@@ -299,7 +299,7 @@ static void run_mix(int iters, unsigned long long* d_out, int blocks, int* sink)
 // 128 x 64), 8 ds_read_b128 (A fragments, conflict-free), 4 buffer loads of 1 KiB (weight fragments, L2-resident panel),
 // 8 address adds, and E requantiser-like VALU instructions (cvt / fma / max / cvt_pk / fract / add / min3 mix) on a second
 // set of 128 registers.  Ideal: 512 cycles per step per wave on its own SIMD (1 wave / SIMD), 1024 with two.
-template <int E>
+template <int E, int MODE>
 __global__ __launch_bounds__(512) void kloop(int steps, unsigned long long* out, int* sink, const unsigned char* gsrc) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -315,13 +315,23 @@ __global__ __launch_bounds__(512) void kloop(int steps, unsigned long long* out,
   unsigned abase[4];
   for (int m = 0; m < 4; ++m) abase[m] = (unsigned)(((m * 32 + (lane & 31)) * 272 + (lane >> 5) * 16) & 0xfff0);
   v4i A[2][4], B[2][2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int m = 0; m < 4; ++m) A[i][m] = v4i{tid, m, i, 3};
+  for (int i = 0; i < 2; ++i)
+    for (int h = 0; h < 2; ++h)
+      for (int n = 0; n < 2; ++n) B[i][h][n] = v4i{tid, h, n, i};
   unsigned kofs = 0;
   auto ldA = [&](v4i (&d)[4], unsigned ko) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) d[m] = *reinterpret_cast<const v4i*>(lds + ((abase[m] + ko) & 0xfff0));
+    for (int m = 0; m < 4; ++m)
+      if (MODE != 4) d[m] = *reinterpret_cast<const v4i*>(lds + ((abase[m] + ko) & 0xfff0));
   };
   auto ldB = [&](v4i (&d)[2][2], int step) {
-    const unsigned base = (unsigned)(((blockIdx.x & 31) * 64 + (step & 63)) * 4096 + (wave & 3) * 0 + lane * 16);
+    if (MODE == 3) return;
+    // MODE 0: every wave of the block reads the same 4 KiB per step; 1: the waves w and w + 4 (one SIMD) share theirs, as the
+    // two pixel halves of i8ie_pconv.hip do; 2: every wave its own
+    const unsigned wsel = MODE == 0 ? 0u : (MODE == 1 ? (unsigned)(wave & 3) : (unsigned)wave);
+    const unsigned base = (unsigned)((((blockIdx.x & 3) * 64 + (step & 63)) * 8 + wsel) * 4096 + lane * 16);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(512) void kloop(int steps, unsigned long long* out,
     out[((size_t)blockIdx.x * 8 + wave) * 2 + 1] = (unsigned long long)steps;
   }
 }
-template <int E>
+template <int E, int MODE>
 static void run_kloop(int steps, unsigned long long* d_out, int blocks, int* sink, const unsigned char* gsrc) {
   std::vector<unsigned long long> h((size_t)blocks * 16);
   auto rate = [&](int w1) {
@@ -388,13 +398,14 @@ static void run_kloop(int steps, unsigned long long* d_out, int blocks, int* sin
     return c / k;
   };
   hipMemset(d_out, 0, h.size() * 8);
-  kloop<E><<<blocks, 256>>>(steps, d_out, sink, gsrc);
+  kloop<E, MODE><<<blocks, 256>>>(steps, d_out, sink, gsrc);
   hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
   const double one = rate(4);
-  kloop<E><<<blocks, 512>>>(steps, d_out, sink, gsrc);
+  kloop<E, MODE><<<blocks, 512>>>(steps, d_out, sink, gsrc);
   hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
   const double two = rate(8);
-  printf("kloop: 16 MFMA + 8 ds_read_b128 + 4 x 1 KiB weight loads + %2d requantiser instructions per k-step of 64: one wave/SIMD %7.1f ticks per step (512 = MFMA rate) | two waves/SIMD %7.1f each (1024)\n", E, one, two);
+  static const char* modes[] = {"weights shared by the block", "weights shared by the SIMD's two waves", "weights per wave", "no weight loads", "no A reads"};
+  printf("kloop [%s]: 16 MFMA + 8 ds_read_b128 + 4 x 1 KiB weight loads + %2d requantiser instructions per k-step of 64: one wave/SIMD %7.1f ticks per step (512 = MFMA rate) | two waves/SIMD: mean %7.1f each, the SIMD's pair of steps %7.1f (1024)\n", modes[MODE], E, one, two, 2 * two - one);
   fflush(stdout);
 }
 
@@ -418,11 +429,15 @@ int main(int argc, char** argv) {
   unsigned char* gsrc;
   hipMalloc(&gsrc, 1u << 24);
   hipMemset(gsrc, 3, 1u << 24);
-  run_kloop<0>(2048, d_out, blocks, sink, gsrc);
-  run_kloop<16>(2048, d_out, blocks, sink, gsrc);
-  run_kloop<32>(2048, d_out, blocks, sink, gsrc);
-  run_kloop<48>(2048, d_out, blocks, sink, gsrc);
-  run_kloop<64>(2048, d_out, blocks, sink, gsrc);
+  run_kloop<0, 0>(2048, d_out, blocks, sink, gsrc);
+  run_kloop<0, 1>(2048, d_out, blocks, sink, gsrc);
+  run_kloop<0, 2>(2048, d_out, blocks, sink, gsrc);
+  run_kloop<0, 3>(2048, d_out, blocks, sink, gsrc);
+  run_kloop<0, 4>(2048, d_out, blocks, sink, gsrc);
+  run_kloop<16, 1>(2048, d_out, blocks, sink, gsrc);
+  run_kloop<32, 1>(2048, d_out, blocks, sink, gsrc);
+  run_kloop<48, 1>(2048, d_out, blocks, sink, gsrc);
+  run_kloop<64, 1>(2048, d_out, blocks, sink, gsrc);
   if (argc > 3 && argv[3][0] == 'k') return 0;
   run_mix<0>(iters, d_out, blocks, sink);
   run_mix<1>(iters, d_out, blocks, sink);
