@@ -69,6 +69,7 @@ int i8ie_sync(i8ie_ctx* ctx);
 #define I8IE_VARIANT_PCONV_2PASS 54    /* the same, N = 384 as two passes of 192 and no 128-wide pass split */
 #define I8IE_VARIANT_TCONV 70          /* two-team patch-stationary conv kernel (csrc/i8ie_tconv.hip) wherever its shape rules allow */
 #define I8IE_VARIANT_FLIN 80           /* few-row Linear kernel (csrc/i8ie_flin.hip) below its automatic feature threshold */
+#define I8IE_VARIANT_FLIN_128 81       /* few-row Linear kernel in its 128-row x 16-feature form at up to 128 rows (default above 64 rows: 64 x 32) */
 /* I8IE_OPT_PROFILE_STRIDE = 3: while profiling, bracket only every value-th eligible launch
  * (default 1 = all).  Event packets cost a few microseconds each on the stream; a stride that is
  * coprime with the launches per batch samples every kernel over a few batches. */

@@ -609,7 +609,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
     }
     I8ieIgemmCall c{};
     // few rows: the one-launch kernel of i8ie_flin.hip (variant 11 keeps the tiled split-K kernel, for comparison)
-    const bool flin = !need_pad && ctx->variant != 11 && L->K % 16 == 0 && i8ie_flin_wants(m, L->n, L->Kpad, ctx->variant == 80);
+    const bool flin = !need_pad && ctx->variant != 11 && L->K % 16 == 0 && i8ie_flin_wants(m, L->n, L->Kpad, ctx->variant == 80 || ctx->variant == 81);
     // split K when the output has too few tiles to fill the chip (small batch, or few features)
     const long tiles_m = (m + 127) / 128, blocks_est = tiles_m * ((L->n + 63) / 64);
     const int nk = L->Kpad / 128;

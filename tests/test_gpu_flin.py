@@ -1,7 +1,8 @@
 """The few-row Linear kernel (csrc/i8ie_flin.hip) against the oracle, through the C-ABI: INT32 accumulators and
 u8 outputs, every element.  Shapes: AlexNet fc6 / fc7 at the 8-GPU shard size (125 rows) and at a full row group
 (128), a single row, 3 rows, K = 1024 (the fewest chunks), K whose chunk count is not a multiple of the stage
-count, N not a multiple of 16 / of 4, with and without the fused ReLU; the tiled split-K kernel (variant 11) must
+count, N not a multiple of 16 / of 4, with and without the fused ReLU; both block shapes (128 rows x 16 features up to 64
+rows, 64 x 32 up to 256 rows incl. the 250-row fc6 of a 4-GPU shard); the tiled split-K kernel (variant 11) must
 give the same bytes.  The profile hooks confirm which kernel ran."""
 import ctypes as C
 
@@ -39,7 +40,13 @@ def _kernels_run(gpu, fn):
 
 
 SHAPES = [(125, 9216, 4096), (125, 4096, 4096), (128, 4096, 4096), (1, 1024, 256), (100, 1280, 272), (17, 2304, 260),
-          (64, 2048, 301), (3, 4096, 4096)]
+          (64, 2048, 301), (3, 4096, 4096),
+          # round 3, the 64-row x 32-feature form (65 .. 256 rows; above 128 rows three LDS stages, two blocks per CU)
+          (65, 2048, 304), (129, 4096, 4096), (250, 9216, 4096), (256, 1280, 272), (200, 1024, 33)]
+
+
+def _kernel_of(m):
+    return "flin_128x16" if m <= 64 else "flin_64x32"
 
 
 @pytest.mark.parametrize("mkn", SHAPES)
@@ -58,12 +65,16 @@ def test_flin_bit_exact(gpu, orc, mkn, relu):
             abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
 
     (out, acc, _), names = _kernels_run(gpu, lambda: run(0 if n >= 2048 else 80))  # (80: below the automatic feature threshold)
-    assert "flin_128x16" in names, names
+    assert _kernel_of(m) in names, names
     want = orc.relu(c["out"], c["zp_out"]) if relu else c["out"]
     assert np.array_equal(acc, c["acc"]) and np.array_equal(out, want)
     (out2, acc2, _), names2 = _kernels_run(gpu, lambda: run(11))
-    assert "flin_128x16" not in names2, names2
+    assert not any(nm.startswith("flin") for nm in names2), names2
     assert np.array_equal(out2, out) and np.array_equal(acc2, acc)
+    if 64 < m <= 128:  # the 128-row form is still there for these row counts (variant 81)
+        (out3, acc3, _), names3 = _kernels_run(gpu, lambda: run(81))
+        assert "flin_128x16" in names3, names3
+        assert np.array_equal(out3, out) and np.array_equal(acc3, acc)
 
 
 def test_flin_extreme_values(gpu, orc):
