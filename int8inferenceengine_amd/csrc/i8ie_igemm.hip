@@ -1027,7 +1027,7 @@ int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, doubl
       return launch_cfg<1, 2, 2, 2, 4, false, false, 5>(ctx, a, "igemm_conv_128x256", kbytes, ops, bytes);
 #endif
     // 192 x 128, 4 waves of 96 x 64, one DMA stage: 6.4 KB staged per MOP (128 x 128: 7.6) at three blocks
-    // per CU; measured 2.5-4 % faster than 128 x 128 on AlexNet conv2-5 (variant 12 = 128 x 128 everywhere)
+    // per CU; measured 2.5-4 % faster than 128 x 128 on AlexNet conv2-5 (any other variant: 128 x 128 everywhere)
     if ((ctx->variant == 0 || ctx->variant == 11) && a.N > 64 && a.M >= 192 * 256)
       return launch_cfg<1, 2, 2, 3, 2, false, false, 5>(ctx, a, "igemm_conv_192x128", kbytes, ops, bytes);
 #if defined(I8IE_DIAG)
