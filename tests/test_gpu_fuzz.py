@@ -172,3 +172,82 @@ def test_random_network_logits_against_oracle(orc, case):
         assert np.array_equal(net(i8ie.tensor(x)).numpy().view(np.uint32), want.view(np.uint32)), entry
     finally:
         del wl.NETWORKS[name]
+
+
+# ---- random MID-SIZE networks at batches of a few hundred images: the shapes the fused kernels are built for (first-stage
+#      kernel with its pool, patch-stationary convs with and without a fused pool, re-biased storage between them, bordered
+#      hand-overs, the few-row / tiled Linear kernels) reached through the i8ie surface with random geometry
+def _random_midsize_network(rng):
+    c = 3
+    h = int(rng.integers(52, 100))
+    w = int(rng.integers(52, 100))
+    layers, spec = {}, []
+    k0 = int(rng.choice([5, 7, 11]))
+    s0 = int(rng.choice([4, 4, 4, 2]))
+    p0 = int(rng.integers(0, k0 // 2 + 1))
+    oc0 = int(rng.choice([32, 64, 96]))
+    layers["conv0"] = ("conv", c, oc0, k0, s0, p0)
+    spec.append(("layer", "conv0"))
+    ch, hh, ww = oc0, (h - k0 + 2 * p0) // s0 + 1, (w - k0 + 2 * p0) // s0 + 1
+    if rng.integers(0, 4):
+        spec.append(("relu",))
+    if s0 == 2 or rng.integers(0, 3) == 0:  # (stride 2 leaves large maps: always pool them)
+        pk, ps = (2, 2) if rng.integers(0, 2) else (3, 2)
+        spec.append(("pool", pk, ps))
+        hh, ww = (hh - pk) // ps + 1, (ww - pk) // ps + 1
+    for i in range(1, int(rng.integers(2, 4))):
+        k = int(rng.choice([3, 3, 5, 1]))
+        pad = int(rng.choice([k // 2, k // 2, 0]))
+        oh, ow = hh - k + 2 * pad + 1, ww - k + 2 * pad + 1
+        if oh < 4 or ow < 4:
+            break
+        oc = int(rng.choice([192, 256, 320, 384]))
+        layers["conv%d" % i] = ("conv", ch, oc, k, 1, pad)
+        spec.append(("layer", "conv%d" % i))
+        ch, hh, ww = oc, oh, ow
+        if rng.integers(0, 5):
+            spec.append(("relu",))
+        if rng.integers(0, 2) and hh >= 4 and ww >= 4:
+            pk, ps = (2, 2) if rng.integers(0, 3) == 0 else (3, 2)
+            spec.append(("pool", pk, ps))
+            hh, ww = (hh - pk) // ps + 1, (ww - pk) // ps + 1
+    feat = ch * hh * ww
+    spec.append(("flatten", feat))
+    dims = [feat, int(rng.choice([64, 256])), 10]
+    for j in range(2):
+        layers["fc%d" % j] = ("fc", dims[j], dims[j + 1])
+        spec.append(("layer", "fc%d" % j))
+        if j == 0:
+            spec.append(("relu",))
+    return layers, spec, (c, h, w)
+
+
+@pytest.mark.parametrize("case", range(max(N_CASES // 8, 6)))
+def test_random_midsize_network_logits_against_oracle(orc, case):
+    import int8inferenceengine_amd  # noqa: F401
+    import i8ie
+    import pipeline
+    from int8inferenceengine_amd import workloads as wl
+
+    rng = np.random.default_rng(90_000 + case)
+    entry = _random_midsize_network(rng)
+    name = "_fuzzmid_%d" % case
+    wl.NETWORKS[name] = entry
+    try:
+        sd = wl.synthetic_state_dict(name, seed=91_000 + case)
+        net = wl.calibrated(name, sd, calib_batch=wl.synthetic_input(name, 16, seed=case))
+        batch = int(rng.choice([200, 260, 330]))
+        x = wl.synthetic_input(name, batch, seed=92_000 + case)
+        got = net(i8ie.tensor(x)).numpy()
+        qlayers = pipeline.quantize_layers(entry, sd)
+        qparams = {a: getattr(net, a).output_qparams() for a in wl.layer_names(name)}
+        want = pipeline.forward(entry, x, qlayers, qparams)
+        assert got.shape == want.shape, (entry, got.shape, want.shape)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (entry, batch)
+        # a second forward (cached weight packings, borders, layouts): same answer; and one at a small batch, where other
+        # kernels take the same layers
+        assert np.array_equal(net(i8ie.tensor(x)).numpy().view(np.uint32), want.view(np.uint32)), (entry, batch)
+        small = net(i8ie.tensor(x[:7])).numpy()
+        assert np.array_equal(small.view(np.uint32), want[:7].view(np.uint32)), (entry, batch)
+    finally:
+        del wl.NETWORKS[name]
