@@ -1,5 +1,9 @@
+"""Which kernels the mid-size random networks of tests/test_gpu_fuzz.py reach (profile hooks around one forward each).
+usage: python tools/midsize_fuzz_coverage.py"""
 import sys, os, collections
-sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import int8inferenceengine_amd
 import i8ie, _CXX_i8ie as cx
@@ -19,7 +23,7 @@ for case in range(40):
     cx.profile_start(mfma_only=False)
     net(x).numpy()
     ents = cx.profile_stop()
-    names = sorted(set(str(e[0] if isinstance(e, (tuple, list)) else e["name"]).split("|")[0] for e in ents))
+    names = sorted(set(str(k).split("|")[0] for k in ents))
     for n in names: tot[n] += 1
     print(case, batch, [(k, v[1:]) for k, v in entry[0].items() if v[0] == "conv"], [s for s in entry[1] if s[0] != "layer"][:6], names, flush=True)
 print(tot)
