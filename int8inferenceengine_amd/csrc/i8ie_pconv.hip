@@ -256,7 +256,8 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
 #pragma unroll
       for (int ni = 0; ni < NTW; ++ni) {
         const int c4[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
-        d[ni] = i8ie_requant_pack4(c4, rq, lo, lof);
+        if constexpr (POOL) d[ni] = i8ie_requant_pack4_norelu(c4, rq);  // (the ReLU follows the pool: pool_pass)
+        else d[ni] = i8ie_requant_pack4(c4, rq, lo, lof);
         if constexpr (ACC) {  // row = image-major pixel index (bands are whole rows), 4 consecutive features per lane
           const int col = n0 + ni * 16 + 4 * lq;
           if (pi < valid && col < p.N)
@@ -319,11 +320,14 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
         pc_divmod(t1, p.PW, p.rcpPW, jr, px);
         const int j = j0 + jr;
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        // maxima start at the ReLU's lower bound (0 without one): max-pool and max(., zp_out) commute, so the epilogue's
+        // requantiser runs without its clamp (src/functional.cc:15-26 behind src/functional.cc:36-64, either order)
+        const unsigned short lo16 = (unsigned short)lo;
         us2 me[4], mo[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          me[q] = us2{0, 0};
-          mo[q] = us2{0, 0};
+          me[q] = us2{lo16, lo16};
+          mo[q] = us2{lo16, lo16};
         }
         int rq0, r0;
         pc_divmod(j * p.ps, p.RB, p.rcpRB, rq0, r0);  // first conv row of the window -> ring row

@@ -61,6 +61,24 @@ __device__ __forceinline__ uint32_t i8ie_requant_pack4(const int (&c)[4], const 
   return packed;
 }
 
+// Without the ReLU (callers that apply max(., zp_out) later, e.g. behind a max-pool, which it commutes with): the
+// estimate needs no lower clamp at all -- v_cvt_pk_u8_f32 saturates at 0 -- so a value costs one instruction less.
+__device__ __forceinline__ uint32_t i8ie_requant_pack4_norelu(const int (&c)[4], const I8ieRequant& q) {
+  uint32_t packed = 0;
+  float worst = q.fast ? 1.0f : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float e = __builtin_fmaf((float)c[r], q.ms, q.zpf - 0.5f);
+    packed = __builtin_amdgcn_cvt_pk_u8_f32(e, r, packed);
+    worst = __builtin_fminf(worst, __builtin_fabsf(__builtin_amdgcn_fractf(e) - 0.5f));
+  }
+  if (worst >= 1.220703125e-4f) return packed;
+  packed = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) packed |= (uint32_t)i8ie_requant_exact((float)c[r], q, 0) << (8 * r);
+  return packed;
+}
+
 // The same in two halves, for epilogues that keep several independent packs in flight without a branch between them:
 // the estimate (+ how far the closest value is from a rounding boundary), and the exact replay for a pack whose
 // `worst` came out below 2^-13 (or whose scales do not allow the estimate: worst = 0 then).
