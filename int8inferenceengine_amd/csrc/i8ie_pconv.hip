@@ -600,8 +600,10 @@ static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   if (RT == 0) return 0;
   if (c.N % 384 == 0 && ctx->variant != 54) {
     const int rt6 = pick_rows(c.N / 384, true);
-    // (only when a whole-chip round of 384-wide bands exists: with few bands the two passes are units of their own)
-    if (rt6 != 0 && (long)n_img * ((c.OH + rt6 - 1) / rt6) >= grid && (rt6 * c.OW + 15) / 16 <= 12 &&
+    // (only when 384-wide bands fill at least 3/4 of a whole-chip round: one such round costs 1.0, two rounds of 192-wide
+    // (band, pass) units 2 x 0.62 (250 images of 13 x 13: 0.105 -> 0.085 ms for conv3 + conv4); with fewer bands the two passes
+    // are units of their own and fit one round)
+    if (rt6 != 0 && (long)n_img * ((c.OH + rt6 - 1) / rt6) * 4 >= (long)grid * 3 && (rt6 * c.OW + 15) / 16 <= 12 &&
         ((RT * c.OW + 15) / 16 <= 12)) {
       bn = 384;
       npass = c.N / 384;
