@@ -144,6 +144,40 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.Bf), 0, p.bf_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
+  // ---- the patch of a tile -> LDS (pixel pitch P: C bytes + one pad chunk), then one xor pass (u8 -> s8)
+  const int CC1 = p.CC + 1;
+  // source offset of granule g relative to the patch origin: the same for every band, so it is tabulated once
+  // (two float divisions per granule at every fill took 2.2-3.7 k cycles per band)
+  auto src_of = [&](int g) {
+    int row, rem, pix, ch;
+    pc_divmod(g, p.row_gran, p.rcpRowGran, row, rem);
+    pc_divmod(rem, CC1, p.rcpCC1, pix, ch);
+    if (pix >= p.Wp) pix = 0;  // (row padding: any readable bytes)
+    return (unsigned)row * p.row_pitch + (unsigned)pix * p.C + (unsigned)(ch < p.CC ? ch : 0) * 16u;
+  };
+  // The block's FIRST fill goes out before anything else (it lands while the tables below are built) and leaves the source
+  // table behind as a by-product: every thread tabulates exactly the granules it will fetch again for the later bands.
+  auto first_fill = [&](int t, int dst) {
+    const int img = t / p.bands, band = t - img * p.bands;
+    const unsigned src0 = (unsigned)img * p.img_pitch + (unsigned)(band * p.RT * p.s) * p.row_pitch;
+    for (int g0 = 0; g0 < p.patch_gran; g0 += 512) {
+      const unsigned rel = src_of(g0 + tid);
+      if (p.lds_src >= 0) reinterpret_cast<unsigned*>(smem + p.lds_src)[g0 + tid] = rel;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(smem + dst + (g0 + wave * 64) * 16), 16,
+                                               (int)(src0 + rel), 0, 0, 0);
+    }
+  };
+  auto patch_fill = [&](int t, int dst) {
+    const int img = t / p.bands, band = t - img * p.bands;
+    const unsigned src0 = (unsigned)img * p.img_pitch + (unsigned)(band * p.RT * p.s) * p.row_pitch;
+    for (int g0 = 0; g0 < p.patch_gran; g0 += 512) {
+      const unsigned so = src0 + (p.lds_src >= 0 ? reinterpret_cast<const unsigned*>(smem + p.lds_src)[g0 + tid] : src_of(g0 + tid));  // (bounds: the descriptor)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(smem + dst + (g0 + wave * 64) * 16), 16,
+                                               (int)so, 0, 0, 0);
+    }
+  };
+  first_fill(p.seq ? unit * p.bands : (p.split ? unit / p.npass : unit), p.lds_patch);
+
   // ---- per-kernel tables in LDS: oc', and for pixel i of a tile its window origin in the patch / its output row
   for (int i = tid; i < p.npass * BN; i += 512) reinterpret_cast<int*>(smem + p.lds_ocp)[i] = i < p.Npad ? p.ocp[i] : 0;
   const int PT = p.RT * p.OW;
@@ -172,29 +206,6 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   }
   const int colb = wn * (NTW * 16);  // first feature of this wave inside the pass
 
-  // ---- the patch of a tile -> LDS (pixel pitch P: C bytes + one pad chunk), then one xor pass (u8 -> s8)
-  const int CC1 = p.CC + 1;
-  // source offset of granule g relative to the patch origin: the same for every band, so it is tabulated once
-  // (two float divisions per granule at every fill took 2.2-3.7 k cycles per band)
-  auto src_of = [&](int g) {
-    int row, rem, pix, ch;
-    pc_divmod(g, p.row_gran, p.rcpRowGran, row, rem);
-    pc_divmod(rem, CC1, p.rcpCC1, pix, ch);
-    if (pix >= p.Wp) pix = 0;  // (row padding: any readable bytes)
-    return (unsigned)row * p.row_pitch + (unsigned)pix * p.C + (unsigned)(ch < p.CC ? ch : 0) * 16u;
-  };
-  if (p.lds_src >= 0) {
-    for (int g = tid; g < p.patch_gran; g += 512) reinterpret_cast<unsigned*>(smem + p.lds_src)[g] = src_of(g);
-  }
-  auto patch_fill = [&](int t, int dst) {
-    const int img = t / p.bands, band = t - img * p.bands;
-    const unsigned src0 = (unsigned)img * p.img_pitch + (unsigned)(band * p.RT * p.s) * p.row_pitch;
-    for (int g0 = 0; g0 < p.patch_gran; g0 += 512) {
-      const unsigned so = src0 + (p.lds_src >= 0 ? reinterpret_cast<const unsigned*>(smem + p.lds_src)[g0 + tid] : src_of(g0 + tid));  // (bounds: the descriptor)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(smem + dst + (g0 + wave * 64) * 16), 16,
-                                               (int)so, 0, 0, 0);
-    }
-  };
   auto patch_xor = [&](int dst) {  // every lane re-biases exactly the granules it fetched itself
     if (p.a_s8) return;            // (the producer stored the bytes re-biased: nothing to do)
     for (int g = tid; g < p.patch_gran; g += 512) {
@@ -387,8 +398,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   auto tile_at = [&](int u, int b) { return p.seq ? u * p.bands + b : (p.split ? u / p.npass : u); };
   auto has_next = [&](int u, int b) { return (p.seq && b + 1 < p.bands) || u + per < t_hi; };
   auto next_tile = [&](int u, int b) { return (p.seq && b + 1 < p.bands) ? tile_at(u, b + 1) : tile_at(u + per, 0); };
-  patch_fill(tile_at(unit, 0), patch);
-  pc_wait_vm<0>();
+  pc_wait_vm<0>();  // (the first patch: requested at the top of the kernel)
   patch_xor(patch);
   if (xpre) {
     load_B(Bq[0], 0, 0);
