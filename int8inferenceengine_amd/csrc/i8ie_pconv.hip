@@ -317,8 +317,8 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
   // ---- POOL: pooled rows [j0, j1) of image img from the LDS ring -> the output tensor.  Thread = (pooled row, pooled
   //      pixel, 16 features): pk x pk ds_read_b128, byte maxima as two v_pk_max_u16 per dword (even / odd bytes spread
   //      by v_perm_b32), one 16-byte store.  Returns the number of store instructions this wave issued.
-  auto pool_pass = [&](int img, int j0, int j1) {
-    const int C16 = p.N >> 4;
+  auto pool_pass = [&](int img, int j0, int j1, int c16_lo, int C16) {  // (features [16 c16_lo, 16 (c16_lo + C16)): all of them,
+                                                                         // or those of the unit's own pass with split)
     const int tasks = (j1 - j0) * p.PW * C16;
     const int PHp = p.PH + 2 * p.ob, PWp = p.PW + 2 * p.ob;
     int nst = 0;
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
       if (id < tasks) {
         int t1, c16, jr, px;
         pc_divmod(id, C16, p.rcpC16, t1, c16);
+        c16 += c16_lo;
         pc_divmod(t1, p.PW, p.rcpPW, jr, px);
         const int j = j0 + jr;
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -469,7 +470,8 @@ __global__ __launch_bounds__(512, 2) void pconv_kernel(PCArgs p) {
       const int oy0 = bnd * p.RT;
       const int hi = oy0 + p.RT < p.OH ? oy0 + p.RT : p.OH;
       const int j0 = rows_done(oy0), j1 = rows_done(hi);
-      const int nst = j1 > j0 ? pool_pass(img, j0, j1) : 0;
+      const int c16n = p.split ? BN / 16 : p.N >> 4;  // (rcpC16 is the reciprocal of this count)
+      const int nst = j1 > j0 ? pool_pass(img, j0, j1, p.split ? pass_lo * (BN / 16) : 0, c16n) : 0;
       if (more) {
         // vector-memory operations retire in issue order: the patch DMA is older than the pool pass's stores (and, with
         // ACC, younger than nothing that matters: ACC kernels just drain)
@@ -688,7 +690,10 @@ static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   const int split = (n_tiles < grid && npass > 1) ? 1 : 0;
   if (ctx->variant == 0 && n_tiles * (split ? npass : 1) < grid * 3 / 4) return 0;
   const int seq = (pool && bands > 1) ? 1 : 0;  // the bands of an image back to back in one block
-  if (pool && (split || (ctx->variant == 0 && n_img < grid * 3 / 4))) return 0;  // (pooling wants whole images per block)
+  // pooling wants whole images per block: bands of an image back to back (seq), or -- whole-image bands whose feature passes
+  // are units of their own (conv5 of a 125-image shard) -- every unit pooling its own features
+  if (pool && split && (bands > 1 || c.N % bn != 0)) return 0;
+  if (pool && !split && ctx->variant == 0 && n_img < grid * 3 / 4) return 0;
   if (dry) return 1;
 
   // ---- fragment-packed weights: once per layer and packing key, kept in the layer handle (I8ieWCache)
@@ -745,7 +750,7 @@ static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   a.a_s8 = c.a_s8;
   a.xor_out = c.out_s8 ? 0x80808080u : 0u;
   a.pk = pool ? c.pool_k : 1; a.ps = pool ? c.pool_s : 1; a.PH = PHo; a.PW = PWo; a.RB = RB; a.opitch = opitch; a.seq = seq;
-  a.rcpPW = 1.0f / (float)PWo; a.rcpC16 = 1.0f / (float)(c.N / 16 > 0 ? c.N / 16 : 1); a.rcpRB = 1.0f / (float)RB;
+  a.rcpPW = 1.0f / (float)PWo; a.rcpC16 = 1.0f / (float)(split ? bn / 16 : (c.N / 16 > 0 ? c.N / 16 : 1)); a.rcpRB = 1.0f / (float)RB;
   a.flags = !split ? 1 : 0;
 #if defined(I8IE_DIAG)
   if (ctx->variant == 53) a.flags = 0;  // (weights fetched at the start of every pass)

@@ -139,6 +139,8 @@ POOL_GEOMS = [
     (257, 256, 13, 13, 384, 3, 1, 1),   # N = 384: one pass of 384
     (70, 32, 20, 20, 256, 3, 1, 1),     # 20 x 20: bands of 12 and 8 rows
     (300, 32, 31, 31, 256, 3, 2, 1),    # stride 2: 16 x 16 outputs
+    (125, 384, 13, 13, 256, 3, 1, 1),   # conv5 of a 125-image shard: (image, pass of 128 features) units, each pools its own features
+    (100, 64, 13, 13, 384, 3, 1, 1),    # N = 384 with few images: (image, pass of 192) units, pooled per pass
 ]
 
 
