@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void probe(int iters, unsigned long long* out,
   if (tid == 0) done = 0;
   for (int i = tid; i < 16384; i += blockDim.x) reinterpret_cast<int*>(lds)[i] = i;
   __syncthreads();
-  const bool mf_wave = MF != 0 && wave < 4;
+  const bool mf_wave = MF != 0 && ((MFP & 16) ? wave >= 4 : wave < 4);  // (MFP bit 4: the MFMA waves are the YOUNGER ones)
   unsigned long long t0 = 0, t1 = 0, n = 0;
   if ((MFP & 4) && !mf_wave) __builtin_amdgcn_s_setprio(3);
   if ((MFP & 8) && mf_wave) __builtin_amdgcn_s_setprio(3);
@@ -207,8 +207,11 @@ static void run_op(const char* name, int iters, unsigned long long* d_out, int* 
   hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
   r16m = rate(0, 4);
   r16v = rate(4, 8);
-  printf("%-22s solo %6.2f | two waves %6.2f each | beside 32x32x32: mfma %6.2f valu %6.2f | beside 16x16x64: mfma %6.2f valu %6.2f | instruction waves at setprio 3: 32x32x32 mfma %6.2f valu %6.2f, 16x16x64 mfma %6.2f valu %6.2f | mfma waves at setprio 3: 16x16x64 mfma %6.2f valu %6.2f\n", name, solo,
-         two, p32m, p32v, p16m, p16v, q32m, q32v, q16m, q16v, r16m, r16v);
+  probe<OP, 17><<<blocks, 512>>>(iters, d_out, sink);
+  hipMemcpy(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost);
+  const double s32m = rate(4, 8), s32v = rate(0, 4);
+  printf("%-22s solo %6.2f | two waves %6.2f each | beside 32x32x32: mfma %6.2f valu %6.2f | beside 16x16x64: mfma %6.2f valu %6.2f | instruction waves at setprio 3: 32x32x32 mfma %6.2f valu %6.2f, 16x16x64 mfma %6.2f valu %6.2f | mfma waves at setprio 3: 16x16x64 mfma %6.2f valu %6.2f | MFMA (32x32x32) on the YOUNGER waves 4-7: mfma %6.2f valu %6.2f\n", name, solo,
+         two, p32m, p32v, p16m, p16v, q32m, q32v, q16m, q16v, r16m, r16v, s32m, s32v);
   fflush(stdout);
 }
 
