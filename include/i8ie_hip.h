@@ -40,6 +40,9 @@ extern "C" {
 
 typedef struct i8ie_ctx i8ie_ctx;     /* one per (thread-of-control, device): stream + workspace */
 typedef struct i8ie_layer i8ie_layer; /* a converted (INT8) Linear or Conv2d with device-resident weights */
+/* Threading: a ctx and the layer handles created on it belong to ONE host thread at a time.  A layer handle caches
+ * state keyed by the call (offset vectors per (s_in, zp_in), weight panels re-packed per kernel shape) without locks:
+ * do not forward the same handle from two host threads at once; one ctx + its own handles per thread is the model. */
 
 /* ---- library / context ------------------------------------------------- */
 const char* i8ie_last_error(void);
@@ -59,7 +62,9 @@ int i8ie_sync(i8ie_ctx* ctx);
  * produce identical bytes; a tuning / A-B timing aid, 0 = default). */
 #define I8IE_OPT_KERNEL_VARIANT 2
 /* The values the product library understands (anything else behaves like 0; the diagnostic build of tools/diag
- * adds timing experiments under further numbers, listed in tools/README.md): */
+ * adds timing experiments under further numbers, listed in tools/README.md).  A value changes the one thing it
+ * names: 3 and 5 also keep the tiled conv at 128 x 128 tiles (0 picks 192 x 128 for large launches), the others
+ * leave the tiled kernel's own defaults alone. */
 #define I8IE_VARIANT_AUTO 0            /* automatic selection per launch */
 #define I8IE_VARIANT_IGEMM_REGSTAGE 3  /* tiled contraction kernel, one LDS stage filled through registers (Linear's default) */
 #define I8IE_VARIANT_IGEMM_DMA 5       /* tiled contraction kernel, one LDS stage filled by LDS-DMA (the tiled conv default) */

@@ -48,6 +48,9 @@ struct I8ieIgemmCall {
   int pool_k, pool_s;  // max_pool2d behind the (relu'd) convolution: `out` is then the pooled tensor, ob its border
   int a_s8, out_s8;    // input bytes / output bytes stored re-biased (^0x80: I8IE_LAYOUT_NHWC_S8)
 };
+// ONE definition of "this call carries a max-pool" for every file: a 1 x 1 window with a stride > 1 subsamples, so it IS a
+// pool (src/functional.cc:36-64 makes no exception for it); kernels that fold pools take k > 1 only and must decline it
+inline bool i8ie_is_pool(int pool_k, int pool_s) { return pool_k > 1 || (pool_k == 1 && pool_s > 1); }
 int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 size_t i8ie_igemm_chunk_limit();  // activations at or beyond this many bytes run as several launches
 

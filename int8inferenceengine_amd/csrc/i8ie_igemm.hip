@@ -1027,8 +1027,11 @@ int launch_tile(i8ie_ctx* ctx, const IgemmArgs& a, int kbytes, double ops, doubl
       return launch_cfg<1, 2, 2, 2, 4, false, false, 5>(ctx, a, "igemm_conv_128x256", kbytes, ops, bytes);
 #endif
     // 192 x 128, 4 waves of 96 x 64, one DMA stage: 6.4 KB staged per MOP (128 x 128: 7.6) at three blocks
-    // per CU; measured 2.5-4 % faster than 128 x 128 on AlexNet conv2-5 (any other variant: 128 x 128 everywhere)
-    if ((ctx->variant == 0 || ctx->variant == 11) && a.N > 64 && a.M >= 192 * 256)
+    // per CU; measured 2.5-4 % faster than 128 x 128 on AlexNet conv2-5.  Only the variants that name a staging form or tile
+    // shape of THIS kernel (3, 5 and the diagnostic 4-10) switch it to 128 x 128; variants that select other kernels (12, 50,
+    // 54, 70, 80, 81 ...) leave the tiled kernel's default alone, so an A/B run with them changes one thing
+    const bool tile_variant = ctx->variant == 3 || ctx->variant == 5 || (ctx->variant >= 4 && ctx->variant <= 10);
+    if (!tile_variant && a.N > 64 && a.M >= 192 * 256)
       return launch_cfg<1, 2, 2, 3, 2, false, false, 5>(ctx, a, "igemm_conv_192x128", kbytes, ops, bytes);
 #if defined(I8IE_DIAG)
     if (ctx->variant == 7 && a.N > 128 && (long)((a.M + 255) / 256) >= 256) {
@@ -1079,7 +1082,7 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   // (the kernel also keeps bordered-output pixel indices in 32 bits)
   const size_t out_pixels = c.amode == 1 ? (size_t)(c.M / (c.OH * c.OW)) * (c.OH + 2 * c.ob) * (c.OW + 2 * c.ob) : 0;
   if (c.a_bytes >= igemm_chunk_limit() || out_pixels >= ((size_t)1 << 32)) {
-    I8IE_REQUIRE(!(c.pool_k > 1 || c.a_s8 || c.out_s8), "igemm: pool / re-biased layout on a launch that needs chunking");
+    I8IE_REQUIRE(!(i8ie_is_pool(c.pool_k, c.pool_s) || c.a_s8 || c.out_s8), "igemm: pool / re-biased layout on a launch that needs chunking");
     const size_t limit = igemm_chunk_limit();
     const int P = c.amode == 1 ? c.OH * c.OW : 1;  // rows per unit (image / row)
     const size_t unit_in = c.amode == 1 ? (size_t)c.Hp * c.Wp * c.C : (size_t)c.lda;
@@ -1133,7 +1136,7 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     if (took != 0) return took < 0 ? took : I8IE_OK;
   }
   // (the kernels below know neither the folded max-pool nor the re-biased layouts: callers ask i8ie_pconv_takes first)
-  I8IE_REQUIRE(!(c.amode == 1 && (c.pool_k > 1 || c.a_s8 || c.out_s8)), "igemm: pool / re-biased layout without the patch-stationary kernel");
+  I8IE_REQUIRE(!(c.amode == 1 && (i8ie_is_pool(c.pool_k, c.pool_s) || c.a_s8 || c.out_s8)), "igemm: pool / re-biased layout without the patch-stationary kernel");
   IgemmArgs a{};
   a.A = c.A;
   a.a_bytes = (unsigned)c.a_bytes;

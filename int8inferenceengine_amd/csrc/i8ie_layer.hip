@@ -506,7 +506,10 @@ static bool stem_takes(const i8ie_layer* L, const ConvGeom& cg, int pool_k, int 
 
 // would the patch-stationary kernel (i8ie_pconv.hip) take this conv launch, with this pool folded in and these
 // re-biased layouts?  (it answers from the geometry and the batch; nothing is launched)
-static bool pconv_probe(i8ie_layer* L, const ConvGeom& cg, int m, int in_border, int pool_k, int pool_s, bool a_s8, bool out_s8) {
+// (`out_border`: the border of the output the real call will write; the size limits of the kernel depend on it.  The layout
+// negotiation queries below do not know it yet and ask with 0: layer_forward_impl asks again with the real one and runs the
+// pool / the re-bias as launches of their own when the kernel then declines)
+static bool pconv_probe(i8ie_layer* L, const ConvGeom& cg, int m, int in_border, int pool_k, int pool_s, bool a_s8, bool out_s8, int out_border = 0) {
   if (!L->conv || L->path != PATH_A || force_fallback(L->ctx)) return false;
   const int b = in_border > cg.pad ? in_border : cg.pad;
   I8ieIgemmCall q{};
@@ -514,7 +517,7 @@ static bool pconv_probe(i8ie_layer* L, const ConvGeom& cg, int m, int in_border,
   q.Kchunks = L->K2 / 16; q.N = L->n; q.wcache = &L->wc; q.OH = cg.oh; q.OW = cg.ow;
   q.Hp = cg.h + 2 * b; q.Wp = cg.w + 2 * b; q.C = cg.c; q.KH = cg.kh; q.KW = cg.kw; q.sh = q.sw = cg.stride;
   q.a_bytes = (size_t)m * q.Hp * q.Wp * cg.c;
-  q.pool_k = pool_k; q.pool_s = pool_s; q.a_s8 = a_s8 ? 1 : 0; q.out_s8 = out_s8 ? 1 : 0;
+  q.pool_k = pool_k; q.pool_s = pool_s; q.a_s8 = a_s8 ? 1 : 0; q.out_s8 = out_s8 ? 1 : 0; q.ob = out_border;
   return q.a_bytes < i8ie_igemm_chunk_limit() && i8ie_pconv_takes(L->ctx, q) == 1;
 }
 
@@ -658,7 +661,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
   // ---- Conv2d --------------------------------------------------------------------------------
   ConvGeom cg;
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
-  const bool pool = pool_k > 1 || (pool_k == 1 && pool_s > 1);
+  const bool pool = i8ie_is_pool(pool_k, pool_s);
   if (pool) I8IE_REQUIRE(pool_k <= cg.oh && pool_k <= cg.ow, "max-pool window larger than the convolution's output");
   const bool in_s8 = in_layout == I8IE_LAYOUT_NHWC_S8, out_s8 = out_layout == I8IE_LAYOUT_NHWC_S8;
   // Which kernel folds what: the first-stage kernel (path B) pools and can store re-biased; the patch-stationary kernel
@@ -668,7 +671,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
   bool pconv = false;
   if (!stem && (pool || in_s8 || out_s8) && out_layout != I8IE_LAYOUT_NCHW && aligned16(in) && aligned16(out) &&
       (acc == nullptr || aligned16(acc)))
-    pconv = pconv_probe(L, cg, m, in_border, pool ? pool_k : 0, pool_s, in_s8, out_s8);
+    pconv = pconv_probe(L, cg, m, in_border, pool ? pool_k : 0, pool_s, in_s8, out_s8, out_border);
   if (in_s8 && !pconv) {  // nobody reads the re-biased bytes as they are: plain copy first
     const size_t bytes = (size_t)m * (cg.h + 2 * in_border) * (cg.w + 2 * in_border) * cg.c;
     uint8_t* tmp = nullptr;
@@ -873,7 +876,7 @@ int i8ie_layer_rebiased_io(const i8ie_layer* L, int m, int h, int w, int pool_k,
   if (!L->conv || m < 1) return I8IE_OK;
   ConvGeom cg;
   if (conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg) != I8IE_OK) return I8IE_OK;
-  const bool pool = pool_k > 1;
+  const bool pool = i8ie_is_pool(pool_k, pool_s);
   if (pool && (pool_s < 1 || pool_k > cg.oh || pool_k > cg.ow)) return I8IE_OK;
   i8ie_layer* Lm = const_cast<i8ie_layer*>(L);
   *reads = pconv_probe(Lm, cg, m, cg.pad, pool ? pool_k : 0, pool_s, true, false) ? 1 : 0;
@@ -900,7 +903,7 @@ int i8ie_layer_forward_f32_input_pool(i8ie_layer* L, const float* in, int m, int
   I8IE_TRY(ensure_offsets(L, q_scale, q_zp));
   ConvGeom cg;
   I8IE_TRY(conv_geom(L->c, h, w, L->n, L->kh, L->kw, L->stride, L->pad, &cg));
-  const bool pool = pool_k > 1 || (pool_k == 1 && pool_s > 1);
+  const bool pool = i8ie_is_pool(pool_k, pool_s);
   if (pool) {
     I8IE_REQUIRE(pool_s > 0 && pool_k <= cg.oh && pool_k <= cg.ow, "max-pool window larger than the convolution's output");
   }

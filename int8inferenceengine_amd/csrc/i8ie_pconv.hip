@@ -561,6 +561,7 @@ int i8ie_pconv_takes(i8ie_ctx* ctx, const I8ieIgemmCall& c) { return pconv_impl(
 
 static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   if (c.amode != 1 || c.biasf != nullptr || c.wcache == nullptr) return 0;
+  if (c.pool_k == 1 && c.pool_s > 1) return 0;  // (a subsampling 1 x 1 pool is a pool, i8ie_is_pool, and this kernel does not fold it)
   const bool pool = c.pool_k > 1;
   if (pool && (c.pool_k > 3 || c.pool_s < 1 || c.pool_s > c.pool_k || c.pool_k > c.OH || c.pool_k > c.OW || c.N % 16 != 0)) return 0;
   if (c.acc != nullptr && ((reinterpret_cast<uintptr_t>(c.acc) & 15u) != 0 || c.N % 4 != 0)) return 0;  // (16-byte accumulator stores)

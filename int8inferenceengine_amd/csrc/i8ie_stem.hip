@@ -657,6 +657,7 @@ struct StemPlan {
 bool stem_plan(int c, int stride, int N, int KH, int KW, int OH, int OW, int pool_k, int pool_s, int parts, StemPlan* out) {
   if (c > 3 || c < 1 || stride < 4 || stride % 4 != 0) return false;
   if (N % 32 != 0 || N < 32 || N > 96) return false;
+  if (pool_k == 1 && pool_s > 1) return false;  // (a subsampling 1 x 1 pool: the caller runs the max-pool kernel behind the conv)
   StemPlan s{};
   const int sq = stride / 4;
   s.KC4 = (KH + 3) / 4;

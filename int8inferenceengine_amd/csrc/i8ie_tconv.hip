@@ -418,7 +418,7 @@ int launch_tc(i8ie_ctx* ctx, const TCArgs& a, int grid, int lds) {
 
 int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   if (c.amode != 1 || c.biasf != nullptr || c.wcache == nullptr) return 0;
-  if (c.pool_k > 1 || c.a_s8 || c.out_s8) return 0;  // (max-pool folding and re-biased layouts: i8ie_pconv.hip)
+  if (i8ie_is_pool(c.pool_k, c.pool_s) || c.a_s8 || c.out_s8) return 0;  // (max-pool folding and re-biased layouts: i8ie_pconv.hip)
   if (c.acc != nullptr && ((reinterpret_cast<uintptr_t>(c.acc) & 15u) != 0 || c.N % 4 != 0)) return 0;  // (16-byte accumulator stores)
   if (c.N % 16 != 0 || c.N < 192 || c.Npad > 1024 || c.C < 32 || c.C % 32 != 0 || c.sh != c.sw) return 0;
   if ((reinterpret_cast<uintptr_t>(c.out) & 15u) != 0) return 0;

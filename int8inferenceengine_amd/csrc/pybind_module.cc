@@ -952,7 +952,7 @@ class BaseLayer {
         check(i8ie_layer_preferred_layout(handle.get(), &out_layout));
         check(i8ie_layer_padding(handle.get(), &pad));
       }
-      const bool pool = pk > 1;
+      const bool pool = pk > 1 || (pk == 1 && ps > 1);  // (a subsampling 1 x 1 window is a pool: the library runs it unfused)
       if (pool && out_layout != I8IE_LAYOUT_NHWC) return nullptr;  // (the caller pools the unfused result)
       std::vector<ssize_t> rshp = oshp;
       if (pool) {

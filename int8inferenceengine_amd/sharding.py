@@ -152,6 +152,17 @@ class ShardedRunner:
     def submit(self, x):
         # (claimed before the forward: a refused submit must not have issued this rank's part of a collective)
         k, tick = self._claim_slot()
+        try:
+            return self._submit_claimed(x, k, tick)
+        except BaseException:
+            # a forward or collective that raised must not leave the slot taken: the next submit on it would then fail with
+            # the "would overwrite" error and hide this one
+            if self._owner[k] == tick:
+                self._owner[k] = None
+                self._tick = tick
+            raise
+
+    def _submit_claimed(self, x, k, tick):
         y = self.forward(x)
         if self.host_copies:
             import torch

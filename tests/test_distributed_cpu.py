@@ -33,3 +33,19 @@ def test_gather_over_gloo(world, n_total):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count(" ok rows ") == world
+
+
+def test_failed_submit_releases_its_ring_slot():
+    """A forward that raises inside submit() must not leave the slot claimed: the error a caller sees later is the
+    forward's, not 'would overwrite the buffers of batch ...' (no process group: the forward raises before any gather)."""
+    calls = {"n": 0}
+
+    def forward(x):
+        calls["n"] += 1
+        raise ValueError("forward failed")
+
+    r = sharding.ShardedRunner(forward, 8, 10, rank=0, world=1, host_copies=True, depth=2)
+    for _ in range(5):  # more failures than slots: each one surfaces as itself
+        with pytest.raises(ValueError, match="forward failed"):
+            r.submit(None)
+    assert calls["n"] == 5 and r._owner == [None, None] and r._tick == 0

@@ -126,8 +126,9 @@ def test_first_stage_from_u8_input(gpu, orc, geom):
     through i8ie_layer_forward_pool / i8ie_layer_forward_fused, incl. an NCHW result and non-default input qparams."""
     n, c, h, w, kc, k, stride, pad = geom
     cs = synth.conv_case(orc, 17 + sum(geom), n, c, h, w, kc, k, stride, pad, s_in=0.031, zp_in=99)
+    # ((1, 2): a subsampling 1 x 1 window is a pool the first-stage kernel does not fold: conv + the max-pool kernel)
     for in_nhwc, out_nhwc, relu, ob, pool in ((False, True, True, 1, (3, 2)), (True, True, False, 0, None),
-                                              (False, False, True, 0, (2, 2))):
+                                              (False, False, True, 0, (2, 2)), (False, True, True, 1, (1, 2))):
         out, acc = gpu.layer_forward_pool(cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"], cs["s_out"],
                                           cs["zp_out"], stride=stride, pad=pad, in_nhwc=in_nhwc, out_nhwc=out_nhwc,
                                           relu=relu, out_border=ob, pool=pool)

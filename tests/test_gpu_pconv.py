@@ -191,3 +191,21 @@ def test_pool_and_rebiased_layouts_where_no_kernel_folds_them(gpu, orc):
                                           in_border=pad, out_border=ob, pool=(3, 2), in_s8=in_s8, out_s8=out_s8, names=names)
         assert not any(nm.startswith("pconv") for nm in names), names
         assert np.array_equal(acc, cs["acc"]) and np.array_equal(out, ref), (in_s8, out_s8, ob)
+
+
+@pytest.mark.parametrize("geom", [POOL_GEOMS[0], POOL_GEOMS[1], (3, 32, 13, 13, 64, 3, 1, 1)])
+def test_subsampling_1x1_pool_is_a_pool_everywhere(gpu, orc, geom):
+    """max_pool2d(kernel_size=1, stride=2) subsamples (src/functional.cc:36-64 has no special case for it).  No kernel folds
+    it, so on launches the patch-stationary kernel would otherwise take (and pool) the library must run conv + the max-pool
+    kernel: the result has the POOLED shape and the oracle's bytes -- round 3 wrote the unpooled tensor into the pooled buffer."""
+    n, c, h, w, kc, k, stride, pad = geom
+    cs = synth.conv_case(orc, 4242 + sum(geom), n, c, h, w, kc, k, stride, pad)
+    ref = orc.max_pool2d(orc.relu(cs["out"], cs["zp_out"]), 1, 2)
+    for in_s8, out_s8, ob in ((False, False, 0), (True, True, 1)):
+        names = []
+        out, acc = gpu.layer_forward_pool(cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"], cs["s_out"],
+                                          cs["zp_out"], stride=stride, pad=pad, in_nhwc=True, out_nhwc=True, relu=True,
+                                          in_border=pad, out_border=ob, pool=(1, 2), in_s8=in_s8, out_s8=out_s8, names=names)
+        assert not any(nm.startswith("pconv_pool") for nm in names), names
+        assert out.shape == ref.shape
+        assert np.array_equal(acc, cs["acc"]) and np.array_equal(out, ref), (in_s8, out_s8, ob)
