@@ -11,6 +11,7 @@ are resident in HBM before the timed region (the notebook builds its tensors
 beforehand, :112-114).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3        (starts the 8 ranks itself, as a child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -60,8 +61,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs one process per GPU: launch with torch.distributed.run" % args.gpus)
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # `python bench.py --gpus N` as typed: one process per GPU is the model, so start the ranks as a CHILD
+            # (torch.distributed.run) and relay its exit code.  Nothing has touched torch or HIP in this process yet, and it
+            # never will: the child does the work (no exec: a process image is never replaced here).
+            import socket
+            import subprocess
+
+            with socket.socket() as s:  # a free rendezvous port on the loopback
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL between processes needs it on this host driver)
+            sys.exit(subprocess.run(cmd, env=env).returncode)  # rank 0's JSON line goes straight to our stdout
         args.gpus = world
     use_dist = world > 1 or args.force_dist
 
@@ -287,7 +301,7 @@ def main():
     # serialises every dispatch) and committed with the commit they were taken at; used only when they describe
     # this kernel at this workload, otherwise null
     traffic, traffic_meta = None, None
-    for cand in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for cand in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
             if tj.get("kernel") == dom and n_total == 1000 and world == 1 and name == "alexnet":
@@ -412,6 +426,7 @@ def main():
         "step_discipline": ("depth-2 software pipeline: batch i+1 is launched before batch i's logits are awaited"
                             if pipelined else "synchronous: logits of batch i read before batch i+1 is launched"),
         ("ms_per_step_synchronous" if pipelined else "ms_per_step_pipelined"): round(other_ms, 4),
+        ("value_synchronous" if pipelined else "value_pipelined"): round(n_total / (other_ms * 1e-3), 1),
         "h2d_ms_fp32_input_pageable_blocking": round(h2d_ms, 2),
         "pcie_inclusive": pcie,
         "fp32_engine_path": {"images_per_sec": round((stop - start) / (fp32_ms * 1e-3), 1), "ms": round(fp32_ms, 1),

@@ -38,3 +38,18 @@ def test_two_ranks_equal_one_rank():
     assert b["scaling"] == "strong" and b["config"]["global_batch"] == 66
     assert a["top1_vs_fp32_teacher"] == b["top1_vs_fp32_teacher"]
     assert "REHEARSAL" in b and b["value"] > 0
+
+
+def test_bench_starts_its_own_ranks_when_typed_without_a_launcher():
+    """`python bench.py --gpus 2 ...` with no launcher: bench.py starts torch.distributed.run as a child process (before it
+    imports torch or touches HIP), relays rank 0's ONE JSON line and the child's exit code."""
+    env = dict(os.environ, I8IE_BENCH_NO_PREWARM="1", I8IE_BENCH_REHEARSE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "66", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["config"]["per_gpu_batch"] == 33 and b["steps"] == 3 and b["value"] > 0
