@@ -72,6 +72,7 @@ int i8ie_sync(i8ie_ctx* ctx);
 #define I8IE_VARIANT_STEM_WHOLE 12     /* first-stage kernel (csrc/i8ie_stem.hip): whole images per block at any batch size (no parts) */
 #define I8IE_VARIANT_PCONV 50          /* patch-stationary conv kernel (csrc/i8ie_pconv.hip) at any batch size */
 #define I8IE_VARIANT_PCONV_2PASS 54    /* the same, N = 384 as two passes of 192 and no 128-wide pass split */
+#define I8IE_VARIANT_DCONV 55          /* deferred-epilogue conv kernel (csrc/i8ie_dconv.hip: one wave per SIMD, the requantiser inside the K loop) where it has shapes */
 #define I8IE_VARIANT_TCONV 70          /* two-team patch-stationary conv kernel (csrc/i8ie_tconv.hip) wherever its shape rules allow */
 #define I8IE_VARIANT_FLIN 80           /* few-row Linear kernel (csrc/i8ie_flin.hip) below its automatic feature threshold */
 #define I8IE_VARIANT_FLIN_128 81       /* few-row Linear kernel in its 128-row x 16-feature form at up to 128 rows (default above 64 rows: 64 x 32) */

@@ -39,81 +39,9 @@
 #include <type_traits>
 #include <vector>
 
-#include "i8ie_calls.h"
-#include "i8ie_internal.h"
-#include "i8ie_requant.h"
+#include "i8ie_pconv_common.h"
 
 namespace {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef unsigned v2u __attribute__((ext_vector_type(2)));
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-
-constexpr unsigned kRowInvalid = 0xC0000000u;  // beyond any output buffer this kernel accepts (< 2^31 bytes)
-constexpr int kTabPix = 256;                   // pixels per tile at most (16 MFMA row tiles)
-
-struct PCArgs {
-  const uint8_t* A;
-  unsigned a_bytes;
-  unsigned img_pitch, row_pitch, C;
-  int OH, OW, s, KH, KW, CC, Wp;
-  float rcpOW, rcpCC1;
-  int RT, bands, n_tiles;  // output rows per tile, tiles per image, tiles in all
-  int P;                   // LDS pixel pitch (bytes) = C + 16
-  int row_gran;            // granules of a patch row in LDS: Wp (CC + 1) + pad, so that consecutive output pixels keep
-                           // walking the 16 slots of 256 B across the row wrap (row pitch / 16 = OW s P / 16 mod 16)
-  float rcpRowGran;
-  int patch_gran;          // 16-byte granules of a full patch
-  const int8_t* Bf;        // [pass][kt][ks][ntile][lane][16]
-  unsigned bf_bytes;
-  int nkt;                 // K tiles of 8 chunks
-  const int* perm;         // [nkt * 8]: source chunk (tap * CC + channel chunk) of K position ci, -1 = zero padding
-  int N, npass;
-  const int32_t* ocp;
-  int Npad;
-  I8ieRequant rq;
-  int relu_lo;
-  uint8_t* out;
-  unsigned out_bytes;
-  int ob, OHp, OWp;
-  int lds_patch, lds_ocp, lds_tab, lds_ktab, lds_src, lds_prog;  // LDS offsets (lds_src < 0: no room for the source table)
-  int split;                // 1: a (band, feature pass) pair is a unit of its own (small batches: more units than CUs)
-  int flags;                // 1 = weights of the next pass fetched by the last K tile (not with split)
-  int32_t* acc;             // ACC kernels: [M][N] pre-requant accumulators (the cblas_gemm_s8u8s32 result, src/conv2d.cc:131-133)
-  int a_s8;                 // 1: the input bytes are stored re-biased already (I8IE_LAYOUT_NHWC_S8): no xor pass over the patch
-  unsigned xor_out;         // 0x80808080: the output is stored re-biased (I8IE_LAYOUT_NHWC_S8), else 0
-  // POOL kernels: max_pool2d (pk x pk, stride ps) behind the (relu'd) convolution.  `out` is then the POOLED tensor
-  // [n][PH + 2 ob][PW + 2 ob][N]; the requantised rows of a band go to an LDS ring of RB conv rows (pixel pitch opitch),
-  // and the bands of an image run back to back in one block (seq) so that the rows a window shares with the previous
-  // band are still there
-  int pk, ps, PH, PW, RB, opitch, lds_otile, seq;
-  float rcpPW, rcpC16, rcpRB;
-  unsigned long long* dbg;  // diagnostic build, variant 51: per block, cycles spent per phase (wave 0); null otherwise
-};
-
-#define PC_BAR() asm volatile("s_barrier" ::: "memory")
-template <int N>
-__device__ __forceinline__ void pc_wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void pc_divmod(int x, int d, float rd, int& qo, int& ro) {  // 0 <= x < 2^23
-  int qq = (int)((float)x * rd);
-  int rr = x - qq * d;
-  if (rr < 0) {
-    rr += d;
-    --qq;
-  } else if (rr >= d) {
-    rr -= d;
-    ++qq;
-  }
-  qo = qq;
-  ro = rr;
-}
-
-extern __shared__ __attribute__((aligned(16))) uint8_t pc_smem[];
-
-// MFMA row r of a 16-row tile <-> pixel offset inside the tile (see the header: even pixels for rows 0-3, 12-15)
-__device__ __forceinline__ int pc_row_to_pix(int r) { return (r < 4) ? 2 * r : (r >= 12 ? 2 * (r - 8) : 2 * (r - 4) + 1); }
 
 // TMW: 16-pixel MFMA tiles per wave (2 waves along the pixels); NTW: 16-feature tiles per wave (4 waves along the
 // features, block = 64 NTW features per pass)
@@ -697,13 +625,20 @@ static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   if (pool && !split && ctx->variant == 0 && n_img < grid * 3 / 4) return 0;
   if (dry) return 1;
 
+  // The deferred-epilogue form (i8ie_dconv.hip: one wave per SIMD, the requantiser of one accumulator set inside the other
+  // set's K loop) is OPT-IN (variant 55).  Round 4 measured it (profiles/r04_dconv_power_limit.txt): 20 % fewer cycles per band
+  // than this file's kernel and 3.0 against 2.6 POPS on constant operands -- but on data whose bits toggle (random bytes, and
+  // the AlexNet step's activations) the chip sits at its power cap either way, its clock falls as the instruction stream gets
+  // denser (1.6 GHz there, 1.9 here) and the step got SLOWER (conv2 + pool 0.469 against 0.405 ms).
+  const bool dconv = ctx->variant == 55 && i8ie_dconv_eligible(split, nkt, npass, patch_gran, PT, bn, pool, c.N);
+
   // ---- fragment-packed weights: once per layer and packing key, kept in the layer handle (I8ieWCache)
   // (a buffer holds [perm: nkt * 8 ints, padded to 256 B][weights]; the fragment order depends on the pass width)
   const size_t perm_bytes = i8ie_align_up((size_t)nkt * 8 * sizeof(int), 256);
   const size_t bf_bytes = (size_t)npass * nkt * kt_bytes;
   const unsigned long long wkey = (1ull << 32) | (unsigned long long)(row_par | (bn << 1));
-  void* wbuf = c.wcache->find(wkey);
-  if (wbuf == nullptr) {
+  void* wbuf = dconv ? nullptr : c.wcache->find(wkey);
+  if (wbuf == nullptr && !dconv) {
     I8IE_REQUIRE(ctx->capture == nullptr, "weight re-packing inside a graph capture: run the same calls once eagerly first");
     I8IE_TRY(i8ie_malloc(ctx, perm_bytes + bf_bytes, &wbuf));
     int rc = i8ie_memcpy_h2d(ctx, wbuf, perm.data(), perm.size() * sizeof(int));
@@ -735,9 +670,11 @@ static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   a.patch_gran = patch_gran;
   a.row_gran = row_gran;
   a.rcpRowGran = 1.0f / (float)row_gran;
-  a.Bf = (const int8_t*)wbuf + perm_bytes;
-  a.perm = (const int*)wbuf;
-  a.bf_bytes = (unsigned)bf_bytes;
+  if (!dconv) {
+    a.Bf = (const int8_t*)wbuf + perm_bytes;
+    a.perm = (const int*)wbuf;
+    a.bf_bytes = (unsigned)bf_bytes;
+  }
   a.nkt = nkt;
   a.N = c.N; a.npass = npass;
   a.ocp = c.ocp; a.Npad = c.Npad;
@@ -771,6 +708,12 @@ static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   snprintf(tag, sizeof(tag), "pconv%s_%dx%d|M%d,N%d,K%d", pool ? "_pool" : "", TMW * 32, bn, c.M, c.N, c.Kchunks * 16);
   char nm[32];
   snprintf(nm, sizeof(nm), "pconv%s_%dx%d", pool ? "_pool" : "", TMW * 32, bn);
+  if (dconv) {
+    tag[0] = 'd';  // "dconv..."
+    nm[0] = 'd';
+    const int rcd = i8ie_dconv_launch(ctx, c, a, perm.data(), PT, bn, grid, lds, ctx->prof ? tag : nm);
+    return rcd == I8IE_OK ? 1 : rcd;
+  }
   I8ieProfScope prof(ctx, ctx->prof ? tag : nm, ops, bytes);
 #if defined(I8IE_DIAG)
   static unsigned long long* dbg_dev[64] = {};  // per device

@@ -61,21 +61,29 @@ def main():
         out = g.empty((n, oh, ow, kc), np.uint8)
         ops = 2.0 * n * oh * ow * kc * c * k * k
         res = {}
+        # I8IE_BENCH_POOL=3,2: the AlexNet layers that are followed by a max-pool (conv2, conv5) run with it folded in
+        pool = [int(v) for v in os.environ["I8IE_BENCH_POOL"].split(",")] if os.environ.get("I8IE_BENCH_POOL") and name in ("conv2", "conv5") else None
+
+        def fwd():
+            if pool:
+                abi.ck(lib.i8ie_layer_forward_pool(L, di.ptr, layout, border, n, h, w, C.c_float(0.025), C.c_uint8(127), 1, pool[0], pool[1],
+                                                   out.ptr, 1, 0, None))
+            else:
+                abi.ck(lib.i8ie_layer_forward_fused(L, di.ptr, layout, border, n, h, w, C.c_float(0.025), C.c_uint8(127), 1, out.ptr, 1, 0, None))
+
         for rep in range(3):
             for v in variants:
                 abi.ck(lib.i8ie_ctx_set_option(g.h, 2, v))
                 for _ in range(3):
-                    abi.ck(lib.i8ie_layer_forward_fused(L, di.ptr, layout, border, n, h, w, C.c_float(0.025),
-                                                        C.c_uint8(127), 1, out.ptr, 1, 0, None))
+                    fwd()
                 g.sync()
                 t0 = time.perf_counter()
                 for _ in range(iters):
-                    abi.ck(lib.i8ie_layer_forward_fused(L, di.ptr, layout, border, n, h, w, C.c_float(0.025),
-                                                        C.c_uint8(127), 1, out.ptr, 1, 0, None))
+                    fwd()
                 g.sync()
                 ms = (time.perf_counter() - t0) / iters * 1e3
                 res.setdefault(v, []).append(ms)
-        print(name, " ".join("v%d: %.4f ms (%.0f TOPS)" % (v, min(t), ops / (min(t) * 1e-3) / 1e12) for v, t in res.items()),
+        print(name + ("+pool" if pool else ""), " ".join("v%d: %.4f ms (%.0f TOPS)" % (v, min(t), ops / (min(t) * 1e-3) / 1e12) for v, t in res.items()),
               flush=True)
         lib.i8ie_layer_destroy(L)
         di.free()
