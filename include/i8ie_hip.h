@@ -75,6 +75,7 @@ int i8ie_sync(i8ie_ctx* ctx);
 #define I8IE_VARIANT_DCONV 55          /* deferred-epilogue conv kernel (csrc/i8ie_dconv.hip: one wave per SIMD, the requantiser inside the K loop) where it has shapes */
 #define I8IE_VARIANT_TCONV 70          /* two-team patch-stationary conv kernel (csrc/i8ie_tconv.hip) wherever its shape rules allow */
 #define I8IE_VARIANT_FLIN 80           /* few-row Linear kernel (csrc/i8ie_flin.hip) below its automatic feature threshold */
+#define I8IE_VARIANT_MLIN 83           /* many-row Linear kernel (csrc/i8ie_mlin.hip) from 257 rows on and below its automatic feature threshold */
 #define I8IE_VARIANT_FLIN_128 81       /* few-row Linear kernel in its 128-row x 16-feature form at up to 128 rows (default above 64 rows: 64 x 32) */
 /* I8IE_OPT_PROFILE_STRIDE = 3: while profiling, bracket only every value-th eligible launch
  * (default 1 = all).  Event packets cost a few microseconds each on the stream; a stride that is

@@ -74,6 +74,11 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 bool i8ie_flin_wants(int m, int n, int Kpad, bool force);
 int i8ie_flin_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
 
+// i8ie_mlin.hip: Linear for many rows (m > 256) in one launch: 128 rows x 128 features x all of K per block (one per CU), both
+// operands through a four-stage LDS-DMA ring fed by dedicated loader waves.  Takes the amode-0 fields of the call.
+bool i8ie_mlin_wants(int m, int n, int Kpad, bool force);
+int i8ie_mlin_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c);
+
 #if defined(I8IE_DIAG)
 // tools/diag/csrc/i8ie_lgemm.hip (diagnostic build, variant 82): Linear for many rows (m > 256): 64 x 128 block tiles, weights
 // straight from L2 in fragment order, activations register-staged through LDS.  Round 3: 57 + 30 us for fc6 + fc7 at 1000

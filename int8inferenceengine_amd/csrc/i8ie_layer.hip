@@ -623,7 +623,10 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
 #else
     const bool lgemm = false;
 #endif
-    if (blocks_est < 256 && nk >= 4 && !flin && !lgemm) {
+    // many rows: the one-launch kernel of i8ie_mlin.hip (variants 3 / 11 keep the tiled kernel, for comparison)
+    const bool mlin = !need_pad && !flin && !lgemm && ctx->variant != 11 && ctx->variant != 3 && L->K % 16 == 0 && aligned16(out) &&
+                      L->Npad % 128 == 0 && i8ie_mlin_wants(m, L->n, L->Kpad, ctx->variant == 83);
+    if (blocks_est < 256 && nk >= 4 && !flin && !lgemm && !mlin) {
       ksplit = (int)((512 + blocks_est - 1) / blocks_est);
       if (ksplit > 8) ksplit = 8;
       if (ksplit > nk / 2) ksplit = nk / 2;
@@ -649,6 +652,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
     c.s_in = s_in; c.s_w = L->s_w; c.s_out = L->s_out; c.zp_out = L->zp_out; c.relu = relu;
     c.out = out; c.ob = 0; c.acc = acc; c.Ktrue = L->K;
     if (flin) return i8ie_flin_launch(ctx, c);
+    if (mlin) return i8ie_mlin_launch(ctx, c);
 #if defined(I8IE_DIAG)
     if (lgemm) {  // (experiment: tools/diag/csrc/i8ie_lgemm.hip)
       c.wcache = &L->wc;
