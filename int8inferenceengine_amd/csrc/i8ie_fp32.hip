@@ -1,7 +1,8 @@
 // i8ie_fp32.hip -- FP32 forward ops used before convert() and during
 // calibration (prepare() -> one FP32 batch -> convert()).  They are off the
-// timed INT8 path: plain, correct, LDS-tiled, not
-// tuned.  The reference computes these with cblas_sgemm
+// timed INT8 path.  Conv2d and Linear run on the f32
+// matrix instruction (round 4); relu / max-pool are plain streaming kernels.
+// The reference computes these with cblas_sgemm
 // (src/conv2d.cc:63-98, src/fully_connected.cc:5-21) and pins them only to
 // atol 0.1 against torch (unittest/test_layers.py:10-11), so summation order
 // is free here.
@@ -10,60 +11,162 @@
 
 namespace {
 
-constexpr int TS = 16;
+// ---- one implicit-GEMM kernel for Conv2d and Linear in FP32 on the f32 matrix instruction -------------------------------
+//   out[r][j] = sum_k X[r][k] * W[j][k] + b[j],   X = im2col(in) (zero padding; src/conv2d.cc:63-98) or in itself (Linear,
+//   src/fully_connected.cc:5-21)
+// v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (64 FLOP per clock and SIMD = the vector rate, 157 TFLOP/s on the chip) and
+// leaves the vector unit to the gathers.  Round 3's kernels were one-thread-per-output VALU loops: 43 ms per launch on AlexNet's
+// convolutions, 1.7 k images/s through the FP32 network (what prepare() / calibration / the FP32 teacher run).
+//   * block = 256 threads, tile = 128 rows (output pixels / input rows) x 128 features, K walked 16 at a time through ONE LDS
+//     stage per operand, k-major ([16][132] floats: a fragment read is 64 consecutive floats, conflict-free); the next K block's
+//     16 + 16 values per thread are in registers before this block's MFMAs start.
+//   * the im2col gather: a row's (image, oy, ox) is worked out once per thread (its row never changes); a K position's
+//     (input offset, kernel row, kernel column) comes from a table of K entries built per launch (k_table_kernel) -- no
+//     division in the loop.
+//   * each wave owns 64 x 64 outputs (2 x 2 MFMA tiles, 64 accumulator registers).  Which operand is srcA decides what a lane
+//     holds: for Conv2d a lane = an output pixel (NCHW stores: 32 consecutive pixels of one feature per instruction), for Linear
+//     a lane = a feature (row-major stores).
+constexpr int FB = 128, FK = 16, FP = 132;  // tile edge, K block, LDS row pitch (floats)
+typedef float v16f __attribute__((ext_vector_type(16)));
 
-// out[i][j] = sum_k in[i][k] * w[j][k] + b[j]      (16x16 LDS tiles)
-__global__ __launch_bounds__(TS* TS) void linear_f32_kernel(const float* __restrict__ in,
-                                                            const float* __restrict__ w,
-                                                            const float* __restrict__ b,
-                                                            float* __restrict__ out, int m, int k, int n) {
-  __shared__ float sa[TS][TS + 1], sb[TS][TS + 1];
-  const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
-  const int row = blockIdx.y * TS + ty, col = blockIdx.x * TS + tx;
-  float acc = 0.0f;
-  for (int k0 = 0; k0 < k; k0 += TS) {
-    const int ar = blockIdx.y * TS + ty, ak = k0 + tx;
-    sa[ty][tx] = (ar < m && ak < k) ? in[(size_t)ar * k + ak] : 0.0f;
-    const int br = blockIdx.x * TS + ty;
-    sb[ty][tx] = (br < n && ak < k) ? w[(size_t)br * k + ak] : 0.0f;
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < TS; ++kk) acc += sa[ty][kk] * sb[tx][kk];
-    __syncthreads();
+struct F32Args {
+  const float* in;
+  const float* w;
+  const float* b;
+  float* out;
+  const int2* ktab;  // [K]: {input offset of K position k relative to the window origin, (kernel row << 16) | kernel column}
+  int M, N, K;
+  int c, h, wd, oh, ow, stride, pad, P;  // P = oh * ow output pixels per image (1 for Linear)
+};
+
+__global__ __launch_bounds__(256) void k_table_kernel(int2* tab, int K, int h, int w, int kh, int kw) {
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+    const int ch = k / (kh * kw), rem = k - ch * (kh * kw), l = rem / kw, m = rem - l * kw;
+    tab[k] = make_int2((ch * h + l) * w + m, (l << 16) | m);
   }
-  if (row < m && col < n) out[(size_t)row * n + col] = acc + b[col];
 }
 
-// direct convolution, one thread per output element, NCHW, zero padding
-__global__ __launch_bounds__(256) void conv2d_f32_kernel(const float* __restrict__ in,
-                                                         const float* __restrict__ wt,
-                                                         const float* __restrict__ b, float* __restrict__ out,
-                                                         int64_t total, int c, int h, int w, int kc, int kh,
-                                                         int kw, int oh, int ow, int stride, int pad) {
-  const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gstride) {
-    const int x = (int)(e % ow);
-    int64_t t = e / ow;
-    const int y = (int)(t % oh);
-    t /= oh;
-    const int j = (int)(t % kc);
-    const int64_t img = t / kc;
-    const int y0 = y * stride - pad, x0 = x * stride - pad;
-    const float* ip = in + img * c * h * w;
-    const float* wp = wt + (size_t)j * c * kh * kw;
-    float acc = 0.0f;
-    for (int ch = 0; ch < c; ++ch)
-      for (int l = 0; l < kh; ++l) {
-        const int yy = y0 + l;
-        if (yy < 0 || yy >= h) continue;
-        for (int mm = 0; mm < kw; ++mm) {
-          const int xx = x0 + mm;
-          if (xx < 0 || xx >= w) continue;
-          acc += ip[((size_t)ch * h + yy) * w + xx] * wp[(ch * kh + l) * kw + mm];
-        }
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(F32Args p) {
+  __shared__ float Xs[FK][FP], Ws[FK][FP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bm0 = blockIdx.y * FB, bn0 = blockIdx.x * FB;
+
+  // ---- this thread's gather row (activations): row bm0 + tid % 128, K positions (tid / 128) + 2 e
+  const int xr = bm0 + (tid & 127), xk0 = tid >> 7;
+  const bool xrow_ok = xr < p.M;
+  const int ximg = xr / p.P, xpix = xr - ximg * p.P;
+  const int xoy = xpix / p.ow, xox = xpix - xoy * p.ow;
+  const int y0 = xoy * p.stride - p.pad, x0 = xox * p.stride - p.pad;
+  const float* xbase = p.in + ((size_t)ximg * p.c * p.h + y0) * (size_t)p.wd + x0;  // (may point before the image: only used with valid taps)
+  // ---- this thread's weight elements: K position tid % 16, features tid / 16 + 16 e
+  const int wk = tid & 15, wj0 = tid >> 4;
+
+  float xv[8], wv[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + xk0 + 2 * e;
+      float v = 0.0f;
+      if (xrow_ok && k < p.K) {
+        const int2 t = p.ktab[k];
+        const int yy = y0 + (t.y >> 16), xx = x0 + (t.y & 0xffff);
+        if (!CONV || ((unsigned)yy < (unsigned)p.h && (unsigned)xx < (unsigned)p.wd)) v = xbase[t.x];
       }
-    out[e] = acc + b[j];
+      xv[e] = v;
+      const int j = bn0 + wj0 + 16 * e, kw_ = k0 + wk;
+      wv[e] = (j < p.N && kw_ < p.K) ? p.w[(size_t)j * p.K + kw_] : 0.0f;
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      Xs[xk0 + 2 * e][tid & 127] = xv[e];
+      Ws[wk][wj0 + 16 * e] = wv[e];
+    }
+  };
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  // srcA's rows become the accumulator's registers, srcB's columns its lanes: Conv2d multiplies (features x K) by (K x pixels),
+  // Linear (rows x K) by (K x features)
+  const int wa = wave >> 1, wb = wave & 1;  // this wave's 64-wide slices of the srcA / srcB tiles
+  const float(*As)[FP] = CONV ? Ws : Xs;
+  const float(*Bs)[FP] = CONV ? Xs : Ws;
+  const int hh = lane >> 5, l31 = lane & 31;
+
+  fetch(0);
+  for (int k0 = 0; k0 < p.K; k0 += FK) {
+    __syncthreads();  // everyone is done with the previous K block
+    stage();
+    __syncthreads();
+    if (k0 + FK < p.K) fetch(k0 + FK);
+#pragma unroll
+    for (int kk = 0; kk < FK; kk += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = As[kk + hh][64 * wa + 32 * i + l31];
+        b[i] = Bs[kk + hh][64 * wb + 32 * i + l31];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
   }
+
+  // ---- + bias, store.  Register 4 g + r of tile (i, j) = srcA row 64 wa + 32 i + 8 g + 4 hh + r, srcB column 64 wb + 32 j + l31
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = 64 * wb + 32 * j + l31;
+    if (CONV) {
+      const int r = bm0 + col;  // output pixel (global row)
+      if (r >= p.M) continue;
+      const int img = r / p.P, pix = r - img * p.P;
+      float* obase = p.out + (size_t)img * p.N * p.P + pix;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int f = bn0 + 64 * wa + 32 * i + 8 * (e >> 2) + 4 * hh + (e & 3);
+          if (f < p.N) obase[(size_t)f * p.P] = acc[i][j][e] + p.b[f];
+        }
+    } else {
+      const int f = bn0 + col;
+      if (f >= p.N) continue;
+      const float bias = p.b[f];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = bm0 + 64 * wa + 32 * i + 8 * (e >> 2) + 4 * hh + (e & 3);
+          if (r < p.M) p.out[(size_t)r * p.N + f] = acc[i][j][e] + bias;
+        }
+    }
+  }
+}
+
+template <bool CONV>
+int launch_gemm_f32(i8ie_ctx* ctx, F32Args a, int kh, int kw, const char* name) {
+  I8IE_REQUIRE((size_t)a.M * a.K < ((size_t)1 << 62) && a.K < (1 << 30), "f32 gemm: dimensions");
+  I8IE_TRY(i8ie_ws_reserve(ctx, (size_t)a.K * sizeof(int2) + 256));
+  int2* tab = reinterpret_cast<int2*>(ctx->ws);
+  k_table_kernel<<<(a.K + 255) / 256 < 64 ? (a.K + 255) / 256 : 64, 256, 0, ctx->stream>>>(tab, a.K, a.h, a.wd, kh, kw);
+  I8IE_LAUNCH_CHECK();
+  a.ktab = tab;
+  const dim3 grid((unsigned)((a.N + FB - 1) / FB), (unsigned)((a.M + FB - 1) / FB));
+  // (blockIdx.y carries the row tiles: 65 535 x 128 = 8.4 M rows per launch; AlexNet's largest, 1000 x 55 x 55, is 3.0 M)
+  I8IE_REQUIRE(grid.y <= 65535u, "f32 gemm: more than 8.4 M output rows in one call");
+  I8ieProfScope prof(ctx, name, 0.0, (double)a.M * a.K * 4 + (double)a.N * a.K * 4 + (double)a.M * a.N * 4);
+  gemm_f32_kernel<CONV><<<grid, 256, 0, ctx->stream>>>(a);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
 }
 
 __global__ __launch_bounds__(256) void relu_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -109,10 +212,11 @@ int i8ie_linear_f32(i8ie_ctx* ctx, const float* in, int m, int k, const float* w
   I8IE_REQUIRE(ctx && in && w && b && out, "null argument");
   I8IE_REQUIRE(m > 0 && k > 0 && n > 0, "non-positive dimension");
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
-  dim3 grid((n + TS - 1) / TS, (m + TS - 1) / TS);
-  linear_f32_kernel<<<grid, TS * TS, 0, ctx->stream>>>(in, w, b, out, m, k, n);
-  I8IE_LAUNCH_CHECK();
-  return I8IE_OK;
+  F32Args a{};
+  a.in = in; a.w = w; a.b = b; a.out = out;
+  a.M = m; a.N = n; a.K = k;
+  a.c = k; a.h = 1; a.wd = 1; a.oh = 1; a.ow = 1; a.stride = 1; a.pad = 0; a.P = 1;
+  return launch_gemm_f32<false>(ctx, a, 1, 1, "linear_f32_mfma");
 }
 
 int i8ie_conv2d_f32(i8ie_ctx* ctx, const float* in, int n, int c, int h, int w, const float* wt,
@@ -122,12 +226,13 @@ int i8ie_conv2d_f32(i8ie_ctx* ctx, const float* in, int n, int c, int h, int w, 
   I8IE_REQUIRE(stride > 0 && pad >= 0, "bad stride/padding");
   I8IE_REQUIRE(h - kh + 2 * pad >= 0 && w - kw + 2 * pad >= 0, "kernel larger than padded input");
   const int oh = (h - kh + 2 * pad) / stride + 1, ow = (w - kw + 2 * pad) / stride + 1;
-  const int64_t total = (int64_t)n * kc * oh * ow;
+  I8IE_REQUIRE((int64_t)n * oh * ow < ((int64_t)1 << 31) && kh < 65536 && kw < 65536, "conv2d_f32: too many output pixels");
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
-  conv2d_f32_kernel<<<cap_grid(total), 256, 0, ctx->stream>>>(in, wt, b, out, total, c, h, w, kc, kh, kw, oh,
-                                                              ow, stride, pad);
-  I8IE_LAUNCH_CHECK();
-  return I8IE_OK;
+  F32Args a{};
+  a.in = in; a.w = wt; a.b = b; a.out = out;
+  a.M = n * oh * ow; a.N = kc; a.K = c * kh * kw;
+  a.c = c; a.h = h; a.wd = w; a.oh = oh; a.ow = ow; a.stride = stride; a.pad = pad; a.P = oh * ow;
+  return launch_gemm_f32<true>(ctx, a, kh, kw, "conv2d_f32_mfma");
 }
 
 int i8ie_relu_f32(i8ie_ctx* ctx, const float* in, float* out, int64_t n) {
