@@ -174,11 +174,21 @@ __device__ __forceinline__ uint32_t calib_draw(uint64_t seed, uint64_t g) {  // 
   return (uint32_t)(((z >> 32) * 2001ull) >> 32);
 }
 // pass 1: the first 1000 values seen fill their slots; a later value that draws slot idx records its position
-// (the LAST one wins, as in the reference's sequential loop)
-__global__ __launch_bounds__(256) void calib_mark_kernel(const float* __restrict__ data, int64_t n, int64_t seen, uint64_t seed,
-                                                         float* __restrict__ samples, int* __restrict__ last) {
+// (the LAST one wins, as in the reference's sequential loop).  Round 4: the last writer of a slot is almost surely among the
+// final few hundred thousand values (a value draws a given slot with probability 1 / 2001), so the TAIL [n - kCalibTail, n) is
+// marked first, and a block of the pass over the head leaves at once unless some slot is still empty (atomicMax keeps the larger
+// index either way: same result as one pass over everything, which cost 8 of the
+// 17 ms of a 100-image calibration forward -- 14 M atomics on 1000 words for conv1's output alone).
+constexpr int64_t kCalibTail = 1 << 18;
+__global__ __launch_bounds__(256) void calib_mark_kernel(const float* __restrict__ data, int64_t lo, int64_t hi, int64_t seen, uint64_t seed,
+                                                         float* __restrict__ samples, int* __restrict__ last, int check_empty) {
+  if (check_empty) {  // (head pass: nothing to do once every slot has its last writer)
+    int e = 0;
+    for (int sl = threadIdx.x; sl < kCalibSlots; sl += 256) e |= last[sl] < 0 ? 1 : 0;
+    if (!__syncthreads_or(e)) return;
+  }
   const int64_t gstride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += gstride) {
+  for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += gstride) {
     const int64_t g = seen + i;
     if (g < kCalibSlots) {
       samples[g] = data[i];
@@ -289,8 +299,19 @@ int i8ie_calib_sample_f32(i8ie_ctx* ctx, const float* data, int64_t n, int64_t s
   I8IE_HIP_TRY(hipSetDevice(ctx->device));
   if (seen_before == 0) I8IE_HIP_TRY(hipMemsetAsync(scratch, 0xFF, kCalibSlots * sizeof(int), ctx->stream));  // all -1
   I8ieProfScope prof(ctx, "calib_sample", 0.0, 4.0 * n);
-  calib_mark_kernel<<<grid_for(n), kThreads, 0, ctx->stream>>>(data, n, seen_before, seed, samples, scratch);
+  const int64_t tail_lo = n > kCalibTail ? n - kCalibTail : 0;
+  calib_mark_kernel<<<grid_for(n - tail_lo), kThreads, 0, ctx->stream>>>(data, tail_lo, n, seen_before, seed, samples, scratch, 0);
   I8IE_LAUNCH_CHECK();
+  if (tail_lo > 0) {
+    // values that fill their own slot (the first kCalibSlots seen) lie in the head: that part always runs
+    const int64_t fill_hi = seen_before < kCalibSlots ? (kCalibSlots - seen_before < tail_lo ? kCalibSlots - seen_before : tail_lo) : 0;
+    if (fill_hi > 0) {
+      calib_mark_kernel<<<grid_for(fill_hi), kThreads, 0, ctx->stream>>>(data, 0, fill_hi, seen_before, seed, samples, scratch, 0);
+      I8IE_LAUNCH_CHECK();
+    }
+    calib_mark_kernel<<<grid_for(tail_lo - fill_hi), kThreads, 0, ctx->stream>>>(data, fill_hi, tail_lo, seen_before, seed, samples, scratch, 1);
+    I8IE_LAUNCH_CHECK();
+  }
   calib_take_kernel<<<(kCalibSlots + 255) / 256, 256, 0, ctx->stream>>>(data, samples, scratch);
   I8IE_LAUNCH_CHECK();
   return I8IE_OK;
