@@ -70,9 +70,9 @@ int i8ie_sync(i8ie_ctx* ctx);
 #define I8IE_VARIANT_IGEMM_DMA 5       /* tiled contraction kernel, one LDS stage filled by LDS-DMA (the tiled conv default) */
 #define I8IE_VARIANT_TILED 11          /* tiled contraction kernel everywhere: no patch-stationary conv, split-K Linear, dot4 head */
 #define I8IE_VARIANT_STEM_WHOLE 12     /* first-stage kernel (csrc/i8ie_stem.hip): whole images per block at any batch size (no parts) */
+#define I8IE_VARIANT_STEM_SIMD_ROLES 13 /* the same with its two wave roles on separate SIMDs (A/B of the placement: 8 % slower, profiles/r04_stem_roles.txt) */
 #define I8IE_VARIANT_PCONV 50          /* patch-stationary conv kernel (csrc/i8ie_pconv.hip) at any batch size */
 #define I8IE_VARIANT_PCONV_2PASS 54    /* the same, N = 384 as two passes of 192 and no 128-wide pass split */
-#define I8IE_VARIANT_DCONV 55          /* deferred-epilogue conv kernel (csrc/i8ie_dconv.hip: one wave per SIMD, the requantiser inside the K loop) where it has shapes */
 #define I8IE_VARIANT_TCONV 70          /* two-team patch-stationary conv kernel (csrc/i8ie_tconv.hip) wherever its shape rules allow */
 #define I8IE_VARIANT_FLIN 80           /* few-row Linear kernel (csrc/i8ie_flin.hip) below its automatic feature threshold */
 #define I8IE_VARIANT_MLIN 83           /* many-row Linear kernel (csrc/i8ie_mlin.hip) from 257 rows on and below its automatic feature threshold */

@@ -19,7 +19,7 @@ CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(ROOT, "include")
 OBJ = os.path.join(PKG, "build")
 
-HIP_SOURCES = ["i8ie_ctx.hip", "i8ie_elementwise.hip", "i8ie_gemm.hip", "i8ie_igemm.hip", "i8ie_pconv.hip", "i8ie_dconv.hip", "i8ie_tconv.hip", "i8ie_first.hip", "i8ie_stem.hip", "i8ie_flin.hip", "i8ie_mlin.hip", "i8ie_layer.hip", "i8ie_fp32.hip"]
+HIP_SOURCES = ["i8ie_ctx.hip", "i8ie_elementwise.hip", "i8ie_gemm.hip", "i8ie_igemm.hip", "i8ie_pconv.hip", "i8ie_tconv.hip", "i8ie_first.hip", "i8ie_stem.hip", "i8ie_flin.hip", "i8ie_mlin.hip", "i8ie_layer.hip", "i8ie_fp32.hip"]
 # -ffp-contract=off: the fp32 epilogue must round exactly like the reference's
 # SSE2 build (no FMA contraction); IEEE divide/sqrt is hipcc's default and is kept.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

@@ -625,12 +625,16 @@ static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   if (pool && !split && ctx->variant == 0 && n_img < grid * 3 / 4) return 0;
   if (dry) return 1;
 
-  // The deferred-epilogue form (i8ie_dconv.hip: one wave per SIMD, the requantiser of one accumulator set inside the other
-  // set's K loop) is OPT-IN (variant 55).  Round 4 measured it (profiles/r04_dconv_power_limit.txt): 20 % fewer cycles per band
+  // The deferred-epilogue form (tools/diag/csrc/i8ie_dconv.hip, diagnostic build, variant 55: one wave per SIMD, the requantiser
+  // of one accumulator set inside the other set's K loop).  Round 4 measured it (profiles/r04_dconv_power_limit.txt): 20 % fewer cycles per band
   // than this file's kernel and 3.0 against 2.6 POPS on constant operands -- but on data whose bits toggle (random bytes, and
   // the AlexNet step's activations) the chip sits at its power cap either way, its clock falls as the instruction stream gets
   // denser (1.6 GHz there, 1.9 here) and the step got SLOWER (conv2 + pool 0.469 against 0.405 ms).
+#if defined(I8IE_DIAG)
   const bool dconv = ctx->variant == 55 && i8ie_dconv_eligible(split, nkt, npass, patch_gran, PT, bn, pool, c.N);
+#else
+  const bool dconv = false;
+#endif
 
   // ---- fragment-packed weights: once per layer and packing key, kept in the layer handle (I8ieWCache)
   // (a buffer holds [perm: nkt * 8 ints, padded to 256 B][weights]; the fragment order depends on the pass width)
@@ -708,12 +712,14 @@ static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   snprintf(tag, sizeof(tag), "pconv%s_%dx%d|M%d,N%d,K%d", pool ? "_pool" : "", TMW * 32, bn, c.M, c.N, c.Kchunks * 16);
   char nm[32];
   snprintf(nm, sizeof(nm), "pconv%s_%dx%d", pool ? "_pool" : "", TMW * 32, bn);
+#if defined(I8IE_DIAG)
   if (dconv) {
     tag[0] = 'd';  // "dconv..."
     nm[0] = 'd';
     const int rcd = i8ie_dconv_launch(ctx, c, a, perm.data(), PT, bn, grid, lds, ctx->prof ? tag : nm);
     return rcd == I8IE_OK ? 1 : rcd;
   }
+#endif
   I8ieProfScope prof(ctx, ctx->prof ? tag : nm, ops, bytes);
 #if defined(I8IE_DIAG)
   static unsigned long long* dbg_dev[64] = {};  // per device

@@ -1,5 +1,5 @@
 // i8ie_pconv_common.h -- what the patch-stationary convolution kernels share (i8ie_pconv.hip: 8 waves, 16 x 16 x 64 MFMA tiles,
-// epilogue behind the K loop; i8ie_dconv.hip: 4 waves with two accumulator sets, 32 x 32 x 32 tiles, the requantiser of one set
+// epilogue behind the K loop; tools/diag/csrc/i8ie_dconv.hip: 4 waves with two accumulator sets, 32 x 32 x 32 tiles, the requantiser of one set
 // inside the other set's K loop): the kernel argument block, the LDS plan it describes, and a few device helpers.
 #pragma once
 #include <cstdint>
@@ -83,7 +83,9 @@ __device__ __forceinline__ int pc_row_to_pix(int r) { return (r < 4) ? 2 * r : (
 
 }  // namespace
 
-// i8ie_dconv.hip: launches the deferred-epilogue kernel for a call pconv_impl (i8ie_pconv.hip) planned; `a` as for pconv_kernel
+#if defined(I8IE_DIAG)
+// tools/diag/csrc/i8ie_dconv.hip (diagnostic build): launches the deferred-epilogue kernel for a call pconv_impl (i8ie_pconv.hip) planned; `a` as for pconv_kernel
 // except Bf / perm (packed for this kernel's fragment order here, cached in the layer handle).  Returns I8IE_OK or an error.
 bool i8ie_dconv_eligible(int split, int nkt, int npass, int patch_gran, int PT, int bn, bool pool, int N);
 int i8ie_dconv_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c, PCArgs a, const int* perm_host, int PT, int bn, int grid, int lds, const char* name);
+#endif

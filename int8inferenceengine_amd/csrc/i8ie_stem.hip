@@ -165,6 +165,9 @@ struct StemArgs {
   float rcpOW;
   unsigned long long* dbg;   // diagnostic build ($I8IE_STEM_STAMPS): per block and wave, cycles per phase; null otherwise
   int dbg_flags;             // diagnostic build ($I8IE_STEM_FLAGS): 1 = vector waves at raised priority
+  int role_split;            // 0: waves 0-3 multiply, 4-7 do the vector work (a multiplying and a vector wave on every SIMD);
+                             // 1: waves 0, 1, 4, 5 multiply, 2, 3, 6, 7 do the vector work (waves w and w + 4 share a SIMD: two
+                             //    SIMDs multiply, two do vector work -- no vector wave sits beside an MFMA stream)
 };
 
 extern __shared__ __attribute__((aligned(16))) uint8_t stem_smem[];
@@ -185,7 +188,10 @@ template <int NG, int KS, bool ACC>
 __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   uint8_t* const smem = stem_smem;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // role and index inside the role (0 .. 3).  `wave` below is the role-relative numbering the rest of the kernel was written
+  // in: 0 .. 3 = the multiplying waves, 4 .. 7 = the vector waves
+  const int wave = p.role_split ? ((wave_hw & 2) << 1) | ((wave_hw >> 2) << 1) | (wave_hw & 1) : wave_hw;
   const int hh = lane >> 5, l31 = lane & 31;
 
   // units (image, part) of this block: b, b + gridDim.x, ...; their strips are walked as one sequence g = 0 .. G - 1.
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   };
   auto stamps_out = [&]() {
     if (p.dbg && lane == 0)
-      for (int i = 0; i < 6; ++i) p.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
+      for (int i = 0; i < 6; ++i) p.dbg[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];  // (role-relative wave number)
   };
 #else
   auto stamp = [](int) {};
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   }
 
   // =============================== vector waves ==============================================================
-  const int vt = tid - 256;  // 0 .. 255
+  const int vt = (wave - 4) * 64 + lane;  // 0 .. 255
   const int vwave = wave - 4;
   // the vector waves are the younger half of the block: at equal priority they get what issue slots the multiplying
   // waves leave (MI355X guide, "two waves per SIMD": +7 % here with the vector waves raised)
@@ -832,6 +838,7 @@ int i8ie_stem_launch(i8ie_ctx* ctx, const I8ieStemCall& c) {
   if (grid > c.n * s.parts) grid = c.n * s.parts;
   const double ops = 2.0 * c.n * c.OH * c.OW * (double)c.N * c.c * c.KH * c.KW;
   const double bytes = (double)c.n * img_pitch + (double)out_bytes;
+  a.role_split = ctx->variant == 13 ? 1 : 0;  // (I8IE_VARIANT_STEM_SIMD_ROLES: A/B of the role placement)
   I8ieProfScope prof(ctx, s.pk > 1 ? "stem_conv_pool" : "stem_conv", ops, bytes);
 #if defined(I8IE_DIAG)
   static unsigned long long* dbg_dev[64] = {};

@@ -51,7 +51,7 @@ def test_random_geometry(gpu, orc, case):
     cs = synth.conv_case(orc, 99 + sum(int(v) for v in case), n, c, h, w, kc, k, stride, pad)
     want = orc.relu(cs["out"], cs["zp_out"]) if relu else cs["out"]
     lib = abi.lib()
-    for variant in (0, 50, 55, 70):
+    for variant in (0, 50, 70):
         abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, variant))
         try:
             out, acc = gpu.layer_forward_fused("conv", cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"],

@@ -36,7 +36,7 @@ def main():
     x = rng.uniform(-2.0, 2.4, (n, c, h, w)).astype(np.float32)
     dx = g.put(x)
     out = g.empty((n, ph + 4, pw + 4, kc), np.uint8)
-    for variant in (0, 11, 0, 11):
+    for variant in [int(v) for v in os.environ.get("I8IE_STEM_VARIANTS", "0,11,0,11").split(",")]:
         abi.ck(lib.i8ie_ctx_set_option(g.h, 2, variant))
         for _ in range(3):
             abi.ck(lib.i8ie_layer_forward_f32_input_pool(L, dx.ptr, n, h, w, C.c_float(0.025), C.c_uint8(127), 1, 3, 2, out.ptr, 1, 2, None))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic build of the C-ABI library: the product sources compiled with -DI8IE_DIAG plus the experiment kernels
 kept here (csrc/i8ie_pp.hip: persistent ping-pong contraction; csrc/i8ie_skinny.hip: few-row Linear; csrc/i8ie_lgemm.hip:
-many-row Linear with weights straight from L2, variant 82), giving
+many-row Linear with weights straight from L2, variant 82; csrc/i8ie_dconv.hip: the deferred-epilogue convolution of round 4,
+variant 55), giving
 tools/diag/libi8ie_hip_diag.so.  Nothing in the package, bench.py or tests/ loads it; point $I8IE_LIB at it:
 
     python tools/diag/build_diag.py
@@ -26,7 +27,7 @@ LIB = os.path.join(HERE, "libi8ie_hip_diag.so")
 def main():
     os.makedirs(OBJ, exist_ok=True)
     srcs = [os.path.join(b.CSRC, s) for s in b.HIP_SOURCES]
-    srcs += [os.path.join(HERE, "csrc", s) for s in ("i8ie_pp.hip", "i8ie_skinny.hip", "i8ie_lgemm.hip")]
+    srcs += [os.path.join(HERE, "csrc", s) for s in ("i8ie_pp.hip", "i8ie_skinny.hip", "i8ie_lgemm.hip", "i8ie_dconv.hip")]
     jobs, objs = [], []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s).replace(".hip", ".o"))

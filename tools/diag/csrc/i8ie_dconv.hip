@@ -66,7 +66,8 @@ constexpr int dc_ops_per_value(bool relu, bool agpr) { return 6 + (relu ? 1 : 0)
 constexpr int dc_ops_per_unit(bool relu, bool agpr) { return 8 * (2 * dc_ops_per_value(relu, agpr) + 1); }  // a unit = one 32 x 32 tile
 #ifndef DC_EXP
 #define DC_EXP 0  // timing experiments (tools/dbg/build_dconv_exp.sh; results are WRONG with any bit set): 1 = no exact-replay code,
-#endif            // 2 = no requantiser in the K loops at all, 4 = no s_nop in front of the MFMAs, 8 = 2 instead of 3 instructions per MFMA
+#endif            // 2 = no requantiser in the K loops at all, 4 = no s_nop in front of the MFMAs, 8 = 2 instead of 3 instructions per MFMA,
+// 16 = phase stamps, 32 = weight fragments fetched for every second K tile only (what do the fetches cost at the power cap?)
 constexpr int kDcOpsPerSlot = (DC_EXP & 8) ? 2 : 3;  // vector instructions behind every MFMA (tools/valu_probe: 3 are free beside a 32x32x32)
 // K tiles (of 4 quarters x TM x NT MFMAs) the requantiser of the other half is spread over
 constexpr int dc_fill_ktiles(int TM, int NT, bool relu) {
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(256, 1) void dconv_kernel(PCArgs p) {
     });
   };
   auto load_B1 = [&](v4i& dst, unsigned kb, int q4, int n) {
+    if ((DC_EXP & 32) && ((kb / (unsigned)KT_BYTES) & 1u)) return;  // (timing experiment: every second K tile reuses stale weights)
     dst = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(kb + (unsigned)((q4 * NT32 + n) * 1024)), 0, 0));
   };
   // One K tile.  On entry: A0 = fragments of quarter 0, kq = its offsets, Bq = its weights.  Quarter q requests, one per MFMA
