@@ -2,7 +2,7 @@
 four-stage LDS ring) against the oracle, through the C-ABI: INT32 accumulators and u8 outputs, every element.  Shapes: AlexNet
 fc6 / fc7 at 1000 and 500 rows, row counts that leave the last row tile ragged (257, 300, 641), K with 4 / 5 / 9 chunks (the
 fewest the ring takes, chunk counts that are not a multiple of the stage count, odd counts: the last step runs without a
-read), N that is not a multiple of 128 / 16 / 4 (partial last feature tile, byte stores), with and without the fused ReLU; the
+read), K that is not a whole number of chunks, N that is not a multiple of 128 / 16 / 4 (partial last feature tile, byte stores), with and without the fused ReLU; the
 tiled kernel (variant 11) must give the same bytes.  The profile hooks confirm which kernel ran."""
 import ctypes as C
 
@@ -40,7 +40,8 @@ def _kernels_run(gpu, fn):
 
 
 SHAPES = [(1000, 9216, 4096), (1000, 4096, 4096), (500, 9216, 4096), (257, 512, 512), (300, 640, 1000), (641, 1152, 520),
-          (384, 2048, 4094), (1000, 1024, 1024)]
+          (384, 2048, 4094), (1000, 1024, 1024),
+          (600, 2000, 2048)]  # K % 128 != 0: the last chunk of a row runs into the next row's bytes, against zero-padded weights
 
 
 def _run(gpu, c, relu, variant):
