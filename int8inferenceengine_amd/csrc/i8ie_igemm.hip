@@ -1124,14 +1124,14 @@ int i8ie_igemm_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
 #endif
   // The two-team form of the patch-stationary kernel (i8ie_tconv.hip) comes first: it declines unless forced
   // (variant 70) or the launch is of the kind it measured faster on (one feature pass, >= 8 bands per CU).
-  if (c.amode == 1 && (ctx->variant == 0 || (ctx->variant >= 70 && ctx->variant < 80))) {
+  if (c.amode == 1 && (i8ie_conv_variant_auto(ctx->variant) || (ctx->variant >= 70 && ctx->variant < 80))) {
     const int took = i8ie_tconv_try_launch(ctx, c);
     if (took != 0) return took < 0 ? took : I8IE_OK;
   }
   // The patch-stationary kernel (i8ie_pconv.hip) takes the large convolutions it is built for (it declines the rest):
   // 2000-2280 TOP/s on AlexNet conv2-5 at 1000 images against 1790-1900 of the tiled kernel below (variant 11 forces
   // the tiled kernel, 50 forces this one at any batch size).
-  if (c.amode == 1 && (ctx->variant == 0 || (ctx->variant >= 50 && ctx->variant < 60))) {
+  if (c.amode == 1 && (i8ie_conv_variant_auto(ctx->variant) || (ctx->variant >= 50 && ctx->variant < 60))) {
     const int took = i8ie_pconv_try_launch(ctx, c);
     if (took != 0) return took < 0 ? took : I8IE_OK;
   }

@@ -303,10 +303,12 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
 }  // namespace
 
 // more rows than the few-row kernel takes, a whole number of 128-byte chunks of K, and enough of them for the four-stage ring
-// (automatic from 5 row tiles on: with 128 blocks or fewer on 256 CUs -- 500 rows x 4096 features -- the tiled kernel's finer tiles
-// are as fast: fc6 + fc7 at 500 rows 73.5 against 71.5 us; `force`, kernel variant 83, lifts that and the feature threshold for tests)
+// (automatic from 4 row tiles on.  On their own -- weights still in the Infinity Cache from the launch before -- the tiled kernel's
+// finer tiles are as fast at 500 rows (fc6 + fc7 73.5 against 71.5 us); INSIDE the AlexNet step, where the weights come from HBM
+// every time, this kernel's touches pay: 0.075 against 0.096 ms at 500 rows, the step 0.713 against 0.747 ms.  At 384 rows (96
+// blocks) the tiled kernel + split-K wins, 0.079 against 0.083.  `force`, kernel variant 83, lifts the thresholds for tests)
 bool i8ie_mlin_wants(int m, int n, int Kpad, bool force) {
-  return m > 256 && (force || (m > 512 && n >= 2048)) && Kpad % kMlChunk == 0 && Kpad >= 4 * kMlChunk;
+  return m > 256 && (force || (m > 384 && n >= 2048)) && Kpad % kMlChunk == 0 && Kpad >= 4 * kMlChunk;
 }
 
 int i8ie_mlin_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {

@@ -617,12 +617,12 @@ static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
   // at 125 images: conv3/conv4 0.028/0.038 ms tiled vs 0.035/0.048 ms here) unless the caller forces this kernel.
   const int n_tiles = n_img * bands;
   const int split = (n_tiles < grid && npass > 1) ? 1 : 0;
-  if (ctx->variant == 0 && n_tiles * (split ? npass : 1) < grid * 3 / 4) return 0;
+  if (i8ie_conv_variant_auto(ctx->variant) && n_tiles * (split ? npass : 1) < grid * 3 / 4) return 0;
   const int seq = (pool && bands > 1) ? 1 : 0;  // the bands of an image back to back in one block
   // pooling wants whole images per block: bands of an image back to back (seq), or -- whole-image bands whose feature passes
   // are units of their own (conv5 of a 125-image shard) -- every unit pooling its own features
   if (pool && split && (bands > 1 || c.N % bn != 0)) return 0;
-  if (pool && !split && ctx->variant == 0 && n_img < grid * 3 / 4) return 0;
+  if (pool && !split && i8ie_conv_variant_auto(ctx->variant) && n_img < grid * 3 / 4) return 0;
   if (dry) return 1;
 
   // The deferred-epilogue form (tools/diag/csrc/i8ie_dconv.hip, diagnostic build, variant 55: one wave per SIMD, the requantiser

@@ -498,7 +498,7 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   // Chosen automatically only where it measured faster than i8ie_pconv.hip: one feature pass, whole patches in the
   // ring, and enough bands per CU to amortise the idle first / last segment of the two teams (AlexNet conv2 at
   // 1000 images: 3000 bands, 2360 vs 2280 TOP/s); variant 70 forces it.
-  if (ctx->variant == 0 && !(npass == 1 && S == 1 && (long)n_img * bands >= 8L * grid)) return 0;
+  if (i8ie_conv_variant_auto(ctx->variant) && !(npass == 1 && S == 1 && (long)n_img * bands >= 8L * grid)) return 0;
   if (S == 2) {
     kt_split = Ksp / 8;
   } else {

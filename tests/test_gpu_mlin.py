@@ -59,7 +59,7 @@ def _run(gpu, c, relu, variant):
 def test_mlin_bit_exact(gpu, orc, mkn, relu):
     m, k, n = mkn
     c = synth.linear_case(orc, 900 + m + k + n, m, k, n)
-    (out, acc, _), names = _kernels_run(gpu, lambda: _run(gpu, c, relu, 0 if (m > 512 and n >= 2048) else 83))  # (83: below the automatic thresholds)
+    (out, acc, _), names = _kernels_run(gpu, lambda: _run(gpu, c, relu, 0 if (m > 384 and n >= 2048) else 83))  # (83: below the automatic thresholds)
     assert "mlin_128x128" in names, names
     want = orc.relu(c["out"], c["zp_out"]) if relu else c["out"]
     assert np.array_equal(acc, c["acc"]) and np.array_equal(out, want)
