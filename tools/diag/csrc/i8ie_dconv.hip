@@ -67,7 +67,8 @@ constexpr int dc_ops_per_unit(bool relu, bool agpr) { return 8 * (2 * dc_ops_per
 #ifndef DC_EXP
 #define DC_EXP 0  // timing experiments (tools/dbg/build_dconv_exp.sh; results are WRONG with any bit set): 1 = no exact-replay code,
 #endif            // 2 = no requantiser in the K loops at all, 4 = no s_nop in front of the MFMAs, 8 = 2 instead of 3 instructions per MFMA,
-// 16 = phase stamps, 32 = weight fragments fetched for every second K tile only (what do the fetches cost at the power cap?)
+// 16 = phase stamps, 32 = weight fragments fetched for every second K tile only (confounded by its branch), 64 = no weight
+// fetches in the K loops, 128 = no activation fragment reads in the K loops (what do the operand streams cost at the power cap?)
 constexpr int kDcOpsPerSlot = (DC_EXP & 8) ? 2 : 3;  // vector instructions behind every MFMA (tools/valu_probe: 3 are free beside a 32x32x32)
 // K tiles (of 4 quarters x TM x NT MFMAs) the requantiser of the other half is spread over
 constexpr int dc_fill_ktiles(int TM, int NT, bool relu) {
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(256, 1) void dconv_kernel(PCArgs p) {
   };
   auto load_B1 = [&](v4i& dst, unsigned kb, int q4, int n) {
     if ((DC_EXP & 32) && ((kb / (unsigned)KT_BYTES) & 1u)) return;  // (timing experiment: every second K tile reuses stale weights)
+    if constexpr ((DC_EXP & 64) != 0) return;                        // (timing experiment: no weight fetches inside the K loops at all)
     dst = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(kb + (unsigned)((q4 * NT32 + n) * 1024)), 0, 0));
   };
   // One K tile.  On entry: A0 = fragments of quarter 0, kq = its offsets, Bq = its weights.  Quarter q requests, one per MFMA
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void dconv_kernel(PCArgs p) {
     auto jobs = [&](auto qc, v4i (&an)[TM], unsigned koff) {
       return [&, koff](auto slc) {
         constexpr int q = decltype(qc)::value, sl = decltype(slc)::value;
-        if constexpr (sl < TM) an[sl] = *reinterpret_cast<const v4i*>(smem + abase[sl] + koff);
+        if constexpr (sl < TM && !(DC_EXP & 128)) an[sl] = *reinterpret_cast<const v4i*>(smem + abase[sl] + koff);  // (128: no activation fragment reads)
         if constexpr (sl >= TM && sl % TM == 0) load_B1(Bq[q][sl / TM - 1], kbn, q, sl / TM - 1);
         if constexpr (sl == U - 1) load_B1(Bq[q][NT - 1], kbn, q, NT - 1);
         if constexpr (q == 0 && sl == (U > TM ? TM : TM - 1)) kqn = load_k(ktn);
