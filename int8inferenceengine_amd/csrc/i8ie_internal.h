@@ -50,7 +50,7 @@ void i8ie_set_error(const char* fmt, ...);
 // I8IE_OPT_KERNEL_VARIANT values that name a Linear kernel (80, 81, 83) or a first-stage form (12, 13) leave the dispatch of the
 // OTHER convolutions automatic (round 3's advice: a variant changes the one thing it names; with 83 set process-wide the conv
 // layers used to lose the patch-stationary kernel their pools were planned for)
-inline bool i8ie_conv_variant_auto(int v) { return v == 0 || v == 12 || v == 13 || v == 80 || v == 81 || v == 83; }
+inline bool i8ie_conv_variant_auto(int v) { return v == 0 || v == 12 || v == 13 || v == 16 || v == 80 || v == 81 || v == 83; }
 
 #define I8IE_HIP_TRY(expr)                                                                  \
   do {                                                                                      \

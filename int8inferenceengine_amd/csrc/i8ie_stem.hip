@@ -30,22 +30,10 @@
 #include <type_traits>
 #include <vector>
 
-#include "i8ie_internal.h"
-#include "i8ie_requant.h"
 #include "i8ie_stem.h"
+#include "i8ie_stem_common.h"
 
 namespace {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
 
 // exact quantize: t = x / scale + zp (fp32 divide, fp32 add), q = ((int)t) & 0xFF (src/quantize_utils.cc:49).
 // Fast path: est = fma(x, fl(1/scale), zp).  For |est| < 1024, |t - est| < 2e-4 (one rounding each of 1/scale and of
@@ -135,54 +123,6 @@ __global__ __launch_bounds__(256) void quantize_s2d_kernel(const void* __restric
   }
 }
 
-constexpr int kStemMaxKS = 14;   // k-steps of 32 bytes
-constexpr int kStemPix = 128;    // pixels of a strip: four 32-pixel MFMA tiles, one per multiplying wave
-
-struct StemArgs {
-  const uint8_t* img;  // s2d image [n][HY][WX][48], bytes re-biased (^0x80)
-  unsigned img_pitch;  // bytes per image
-  int n_img;
-  int WX, rowB;        // s2d pixels per row; bytes per s2d row
-  int OH, OW, sq;      // conv output dims; stride / 4
-  int KC4, RC, nch;    // s2d rows a window spans; 16-byte chunks per run (3 x s2d pixels per run); chunks in all
-  int NR, first, T;    // conv rows per strip; rows of a part's first strip; strips per part (the longest part's count)
-  int parts, lg_parts; // an image is cut into 2^lg_parts parts of whole pooled rows, each a unit of its own (small batches:
-                       // more units than CUs); a part recomputes the pk - ps conv rows it shares with the part above it
-  int pk, ps, PH, PW;  // pool window / stride (1, 1 = no pool), output dims after the pool
-  const int8_t* B;     // [N][Kpad] K ordered (s2d row, s2d px, row-in-4, px-in-4, ch), zero padded
-  int Kpad, N;
-  const int32_t* ocp;
-  I8ieRequant rq;
-  int relu_lo;
-  uint8_t* out;  // NHWC [n][PH + 2 ob][PW + 2 ob][N]
-  int ob;
-  unsigned xor_out;  // 0, or 0x80808080: output stored re-biased (I8IE_LAYOUT_NHWC_S8)
-  int32_t* acc;      // ACC kernels: [n * OH * OW][N] pre-requant accumulators of the convolution
-  int pitchP, ringRowB, RING;           // INT32 ring: bytes per pixel (4 N + 16), per conv row, rows
-  int patchB;                            // bytes of a patch buffer (whole 1 KiB pieces)
-  int lds_patch, lds_ring, lds_ocp, lds_tab, lds_adv, lds_dump, lds_bfrag;  // LDS offsets (lds_dump: 2 KiB that lanes past a strip's last pixel store into; lds_bfrag: the last feature group's weights)
-  unsigned out_bytes;
-  float rcpOW;
-  unsigned long long* dbg;   // diagnostic build ($I8IE_STEM_STAMPS): per block and wave, cycles per phase; null otherwise
-  int dbg_flags;             // diagnostic build ($I8IE_STEM_FLAGS): 1 = vector waves at raised priority
-  int role_split;            // 0: waves 0-3 multiply, 4-7 do the vector work (a multiplying and a vector wave on every SIMD);
-                             // 1: waves 0, 1, 4, 5 multiply, 2, 3, 6, 7 do the vector work (waves w and w + 4 share a SIMD: two
-                             //    SIMDs multiply, two do vector work -- no vector wave sits beside an MFMA stream)
-};
-
-extern __shared__ __attribute__((aligned(16))) uint8_t stem_smem[];
-
-// workgroup barrier that waits for this wave's LDS operations only: vector-memory operations (the patch DMA two strips
-// ahead, the output stores) stay in flight across it (__syncthreads() would drain them: s_waitcnt vmcnt(0))
-#define STEM_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-// Strip t of an image, tabulated once per block in LDS (8 ints): the scalar arithmetic of a strip is then two LDS reads
-//   [0] lo, [1] hi: conv rows [lo, hi)          [2] byte offset of its patch inside the image, [3] bytes of the patch
-//   [4] j0, [5] j1: pooled rows it completes    [6] lo % RING, [7] (j0 * ps) % RING
-struct StemStrip {
-  int lo, hi, poff, pbytes, j0, j1, lom, jm;
-};
-
 // NG: 32-feature groups (N = 32 NG); KS: k-steps; ACC: also dump the INT32 accumulators (acc_dbg of the C-ABI)
 template <int NG, int KS, bool ACC>
 __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
@@ -212,36 +152,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     *reinterpret_cast<v4i*>(smem + p.lds_bfrag + i * 16) =
         *reinterpret_cast<const v4i*>(p.B + (size_t)((NG - 1) * 32 + (ln & 31)) * p.Kpad + j * 32 + (ln >> 5) * 16);
   }
-  if (tid < T * p.parts) {  // (T * parts <= 256: checked on the host)
-    int part = 0, t = tid;
-    while (t >= T) {
-      t -= T;
-      ++part;
-    }
-    // part = pooled rows [J0, J1) = conv rows [R0, R1); its strips: `first` rows, then NR at a time (empty past the end)
-    const int J0 = part * p.PH / p.parts, J1 = (part + 1) * p.PH / p.parts;
-    const int R0 = J0 * p.ps, R1 = part + 1 == p.parts ? p.OH : (J1 - 1) * p.ps + p.pk;
-    auto hi_of = [&](int tt) { const int v = R0 + p.first + tt * p.NR; return v < R1 ? v : R1; };
-    auto done = [&](int hi) {  // pooled rows of the image whose window ends at or below conv row hi, inside this part
-      if (hi < p.pk) return J0;
-      int e = (hi - p.pk) / p.ps + 1;
-      e = e < J1 ? e : J1;
-      return e > J0 ? e : J0;
-    };
-    StemStrip e;
-    e.hi = hi_of(t);
-    e.lo = t == 0 ? R0 : hi_of(t - 1);
-    const int rows = e.hi > e.lo ? (e.hi - e.lo - 1) * p.sq + p.KC4 : 0;
-    e.poff = e.lo * p.sq * p.rowB;
-    e.pbytes = rows * p.rowB;
-    if ((unsigned)(e.poff + e.pbytes) > p.img_pitch) e.pbytes = (int)p.img_pitch - e.poff;  // (never: the image holds every window row)
-    e.j1 = done(e.hi);
-    e.j0 = t == 0 ? J0 : done(e.lo);
-    e.lom = (e.lo - R0) % RING;
-    e.jm = (e.j0 * p.ps - R0) % RING;
-    reinterpret_cast<StemStrip*>(smem + p.lds_tab)[tid] = e;
-    if (t == 0) reinterpret_cast<int*>(smem + p.lds_adv)[part] = (R1 - R0) % RING;
-  }
+  stem_fill_tables(p, smem, tid, T, RING);
   __syncthreads();  // (every wave, before the roles part: the tables are read from here on)
   auto strip = [&](int unit, int t) {  // (wave-uniform: the entry lands in SGPRs)
     const int idx = (unit & pmask) * T + t;
@@ -460,7 +371,11 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   const int pl = gi & 7;                               // pixel inside the task's 8
   const int ql = 2 * (2 * hh + hg) + (gi >> 3);        // feature quad inside the task's 8
   const int nqo = N4 >> 3, npo = (p.PW + 7) >> 3, ntask = nqo * npo;
-  const int rd_lane = pl * p.ps * p.pitchP + ql * 16;  // LDS byte offset of this lane's window origin inside a task
+  // bytes of a ring pixel, known here (the host's pitchP: 4 N + 16 with N = 32 NG): the window's dx steps become the
+  // immediate offsets of the ds_read_b128 instead of a vector add each -- the vector waves pay ~9 cycles per instruction
+  // of any kind beside an MFMA stream (phase stamps), and a third of a pool round's instructions were address arithmetic
+  constexpr int PITCH = NG * 128 + 16;
+  const int rd_lane = pl * p.ps * PITCH + ql * 16;  // LDS byte offset of this lane's window origin inside a task
   const int st_lane = pl * p.N + ql * 4;               // output byte offset of this lane inside a task
 
   // A wave's pool tasks: k = vwave + 4 u (+ 12 per further round); task k = (pixel octet po, quad octet qo).  What does
@@ -471,51 +386,50 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     int rd, st, oc;
   };
   auto task_of = [&](int k) {
-    int po = k, qo = 0;  // k = qo * npo + po
+    int po = k < ntask ? k : 0, qo = 0;  // k = qo * npo + po
     while (po >= npo) {
       po -= npo;
       ++qo;
     }
     const bool ok = 8 * po + pl < p.PW;
     PoolTask t;
-    t.rd = (ok ? rd_lane : ql * 16) + (8 * po) * p.ps * p.pitchP + qo * 128;
-    t.st = ok ? (8 * po) * p.N + qo * 32 + st_lane : (int)0x80000000;
+    t.rd = (ok ? rd_lane : ql * 16) + (8 * po) * p.ps * PITCH + qo * 128;
+    t.st = ok && k < ntask ? (8 * po) * p.N + qo * 32 + st_lane : (int)0x80000000;  // (a task past the row's last: stored nowhere)
     t.oc = p.lds_ocp + (qo * 8 + ql) * 16;
     return t;
   };
   PoolTask tk0[UN];
 #pragma unroll
-  for (int u = 0; u < UN; ++u) tk0[u] = task_of(vwave + 4 * u < ntask ? vwave + 4 * u : 0);
+  for (int u = 0; u < UN; ++u) tk0[u] = task_of(vwave + 4 * u);
+  v4i oc0[UN];  // oc' of the first round's tasks: the same for every pooled row (the table is complete: barrier above)
+#pragma unroll
+  for (int u = 0; u < UN; ++u) oc0[u] = *reinterpret_cast<const v4i*>(smem + tk0[u].oc);
   // pooled rows [j0, j1) of image im (ring base ib): max over the INT32 window, + oc', requantise, store.  The (up to
   // three) tasks of a round run side by side without a branch between them: all window reads first, then three
   // independent chains of maxima and requantiser -- one wave per SIMD does this work, nothing else covers its latencies
   auto pool_rows = [&](auto pkc, int im, int ib, const StemStrip& e) {
     constexpr int PK = decltype(pkc)::value;
-    int rm = e.jm;  // (j * ps) % RING of the row's first conv row
+    int rm = ib + e.jm;  // ring slot of the row's first conv row: (ib + (j * ps) % RING) % RING
+    if (rm >= RING) rm -= RING;
     for (int j = e.j0; j < e.j1; ++j) {
       int rowoff[PK];
 #pragma unroll
       for (int dy = 0; dy < PK; ++dy) {
-        int sl = ib + rm + dy;
-        while (sl >= RING) sl -= RING;
-        rowoff[dy] = p.lds_ring + sl * p.ringRowB;
+        const int sl = rm + dy;
+        rowoff[dy] = p.lds_ring + (sl >= RING ? sl - RING : sl) * p.ringRowB;
       }
       const int orow = ((im * PHp + j + p.ob) * PWp + p.ob) * p.N;
-      for (int k0 = vwave; k0 < ntask; k0 += 4 * UN) {
-        PoolTask tk[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) tk[u] = k0 == vwave ? tk0[u] : task_of(k0 + 4 * u < ntask ? k0 + 4 * u : 0);
-        const int nu = (ntask - k0 + 3) >> 2;  // tasks of this round that exist (wave-uniform; the rest is computed and dropped)
+      // one round: UN tasks side by side (tasks past the row's last are computed and stored nowhere)
+      auto round = [&](const PoolTask (&tk)[UN], const v4i (&ocv)[UN]) {
         v4i v[UN][PK * PK];
 #pragma unroll
         for (int u = 0; u < UN; ++u)
 #pragma unroll
-          for (int dy = 0; dy < PK; ++dy)
+          for (int dy = 0; dy < PK; ++dy) {
+            const uint8_t* const a = smem + (rowoff[dy] + tk[u].rd);  // one vector add per window row; dx: immediate offsets
 #pragma unroll
-            for (int dx = 0; dx < PK; ++dx) v[u][dy * PK + dx] = *reinterpret_cast<const v4i*>(smem + rowoff[dy] + tk[u].rd + dx * p.pitchP);
-        v4i ocv[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) ocv[u] = *reinterpret_cast<const v4i*>(smem + tk[u].oc);
+            for (int dx = 0; dx < PK; ++dx) v[u][dy * PK + dx] = *reinterpret_cast<const v4i*>(a + dx * PITCH);
+          }
 #if defined(I8IE_DIAG)
         stamp(1);  // (pool pass: scalar part, addresses, read issue)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -547,15 +461,22 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
             if (!i8ie_requant_est_ok(worst[u])) d[u] = i8ie_requant_exact4(c4[u], rq, lo_relu);
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-          if (u < nu) {
-            __builtin_amdgcn_raw_buffer_store_b32(d[u] ^ p.xor_out, rsO, tk[u].st, orow, 0);
-          }
-        }
+        for (int u = 0; u < UN; ++u) __builtin_amdgcn_raw_buffer_store_b32(d[u] ^ p.xor_out, rsO, tk[u].st, orow, 0);
         stamp(5);  // (pool pass: maxima, requantiser, stores)
+      };
+      round(tk0, oc0);
+      for (int k0 = vwave + 4 * UN; k0 < ntask; k0 += 4 * UN) {  // (more than 12 tasks to a pooled row: none of AlexNet's)
+        PoolTask tk[UN];
+        v4i ocv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          tk[u] = task_of(k0 + 4 * u);
+          ocv[u] = *reinterpret_cast<const v4i*>(smem + tk[u].oc);
+        }
+        round(tk, ocv);
       }
       rm += p.ps;
-      while (rm >= RING) rm -= RING;
+      if (rm >= RING) rm -= RING;
     }
   };
   auto dump_acc = [&](int im, int ib, const StemStrip& e) {  // conv rows [lo, hi) of the image: ring -> acc_dbg
@@ -839,6 +760,9 @@ int i8ie_stem_launch(i8ie_ctx* ctx, const I8ieStemCall& c) {
   const double ops = 2.0 * c.n * c.OH * c.OW * (double)c.N * c.c * c.KH * c.KW;
   const double bytes = (double)c.n * img_pitch + (double)out_bytes;
   a.role_split = ctx->variant == 13 ? 1 : 0;  // (I8IE_VARIANT_STEM_SIMD_ROLES: A/B of the role placement)
+#if defined(I8IE_DIAG)
+  const bool fused = s.pk == 3 && ctx->variant == 16;  // (tools/diag/csrc/i8ie_stem_fused.hip: every wave in both roles)
+#endif
   I8ieProfScope prof(ctx, s.pk > 1 ? "stem_conv_pool" : "stem_conv", ops, bytes);
 #if defined(I8IE_DIAG)
   static unsigned long long* dbg_dev[64] = {};
@@ -850,7 +774,7 @@ int i8ie_stem_launch(i8ie_ctx* ctx, const I8ieStemCall& c) {
   }
   if (const char* e = std::getenv("I8IE_STEM_FLAGS")) a.dbg_flags = std::atoi(e);
   struct Report {
-    i8ie_ctx* ctx; unsigned long long* d; int grid, strips; bool on;
+    i8ie_ctx* ctx; unsigned long long* d; int grid, strips; bool on, fused;
     ~Report() {
       if (!on) return;
       std::vector<unsigned long long> h((size_t)grid * 64);
@@ -861,15 +785,24 @@ int i8ie_stem_launch(i8ie_ctx* ctx, const I8ieStemCall& c) {
         for (int w = 0; w < 8; ++w)
           for (int i = 0; i < 6; ++i) sm[w][i] += (double)h[((size_t)b * 8 + w) * 8 + i];
       const double n = (double)strips;  // strips in all (sum over blocks)
+      if (fused) {
+        fprintf(stderr, "stem_stamps (every wave in both roles): %d strips; per strip, cycles [region | ring stores + rest of the pool pass | patch wait + barrier]:", strips);
+        for (int w = 0; w < 8; ++w) fprintf(stderr, " w%d %.0f|%.0f|%.0f", w, sm[w][0] / n, sm[w][1] / n, sm[w][2] / n);
+        fprintf(stderr, "\n");
+        return;
+      }
       fprintf(stderr, "stem_stamps: %d strips; per strip, cycles: multiplying waves [mfma | ring write | barrier]:", strips);
       for (int w = 0; w < 4; ++w) fprintf(stderr, " w%d %.0f|%.0f|%.0f", w, sm[w][0] / n, sm[w][1] / n, sm[w][2] / n);
       fprintf(stderr, " ; vector waves [patch request | pool: issue, reads landing, compute | patch wait | barrier]:");
       for (int w = 4; w < 8; ++w) fprintf(stderr, " w%d %.0f|%.0f,%.0f,%.0f|%.0f|%.0f", w, sm[w][0] / n, sm[w][1] / n, sm[w][4] / n, sm[w][5] / n, sm[w][2] / n, sm[w][3] / n);
       fprintf(stderr, "\n");
     }
-  } report{ctx, a.dbg, grid, c.n * s.T * s.parts, a.dbg != nullptr};
+  } report{ctx, a.dbg, grid, c.n * s.T * s.parts, a.dbg != nullptr, fused};
 #endif
   const int NG = c.N / 32;
+#if defined(I8IE_DIAG)
+  if (fused) return i8ie_stem_fused_launch(ctx, a, NG, s.KS, grid, s.lds);
+#endif
 #define I8IE_STEM_KS(NGV)                                                   \
   if (s.KS <= 6) return launch_stem<NGV, 6>(ctx, a, grid, s.lds);           \
   if (s.KS <= 10) return launch_stem<NGV, 10>(ctx, a, grid, s.lds);         \

@@ -27,7 +27,7 @@ LIB = os.path.join(HERE, "libi8ie_hip_diag.so")
 def main():
     os.makedirs(OBJ, exist_ok=True)
     srcs = [os.path.join(b.CSRC, s) for s in b.HIP_SOURCES]
-    srcs += [os.path.join(HERE, "csrc", s) for s in ("i8ie_pp.hip", "i8ie_skinny.hip", "i8ie_lgemm.hip", "i8ie_dconv.hip")]
+    srcs += [os.path.join(HERE, "csrc", s) for s in ("i8ie_pp.hip", "i8ie_skinny.hip", "i8ie_lgemm.hip", "i8ie_dconv.hip", "i8ie_stem_fused.hip")]
     jobs, objs = [], []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s).replace(".hip", ".o"))
