@@ -33,6 +33,12 @@
 #include "i8ie_stem.h"
 #include "i8ie_stem_common.h"
 
+// who requests a strip's patch (LDS-DMA): 1 = the vector waves, 0 = the multiplying waves.  Measured both ways on one box
+// (tools/dbg/build_stem_ab.sh wt wt-DSTEM_DMA_VEC=1): 0.240 ms from the multiplying waves, 0.245 from the vector waves
+#if !defined(STEM_DMA_VEC)
+#define STEM_DMA_VEC 0
+#endif
+
 namespace {
 
 // exact quantize: t = x / scale + zp (fp32 divide, fp32 add), q = ((int)t) & 0xFF (src/quantize_utils.cc:49).
@@ -169,8 +175,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   // strip after the one they are about to multiply; awaited before the interval's barrier): they have the slack -- the
   // vector waves are the kernel's critical path, and three pieces cost a wave ~700 cycles of issue (phase stamps)
   auto adv_of = [&](int unit) { return __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(smem + p.lds_adv)[unit & pmask]); };
-  auto patch_dma = [&](int unit, int t, int pb) {
-    const StemStrip e = strip(unit, t);
+  auto patch_dma = [&](int unit, const StemStrip& e, int pb) {
     if (e.pbytes <= 0) return;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(p.img + (size_t)(unit >> p.lg_parts) * p.img_pitch + (unsigned)e.poff), 0, e.pbytes, 0x00020000);
@@ -235,7 +240,9 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         imn += (int)gridDim.x;
       }
     };
-    patch_dma(imn, tn, 0);
+    StemStrip e = strip(imn, tn);  // the strip multiplied in the coming interval (one table lookup per strip: it is read when
+                                   // its patch is requested, an interval ahead)
+    patch_dma(imn, e, 0);
     next_n();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STEM_BAR();  // (the first patch)
@@ -243,11 +250,12 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     if (p.dbg) tq = __builtin_amdgcn_s_memtime();
 #endif
     for (int g = 0; g < G; ++g) {
+      StemStrip en{};
       if (g + 1 < G) {  // the patch of strip g + 1 -> the other buffer (strip g - 1 was its last reader)
-        patch_dma(imn, tn, pbuf ^ 1);
+        en = strip(imn, tn);
+        if (!STEM_DMA_VEC) patch_dma(imn, en, pbuf ^ 1);
         next_n();
       }
-      const StemStrip e = strip(un, t);
       const int npx = (e.hi - e.lo) * p.OW;
       if (wave * 32 < npx) {  // (wave-uniform: a short strip leaves the upper tiles without work)
         const bool valid = pp < npx;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         stamp(1);  // ring writes
 #endif
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patch requested at the top of the interval has landed
+      if (!STEM_DMA_VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patch requested at the top of the interval has landed
       STEM_BAR();
       stamp(2);  // at the barrier
       if (++t == T) {
@@ -339,6 +347,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         un += (int)gridDim.x;
       }
       pbuf ^= 1;
+      e = en;
     }
     STEM_BAR();  // the vector waves' last interval
     stamps_out();
@@ -407,6 +416,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   // pooled rows [j0, j1) of image im (ring base ib): max over the INT32 window, + oc', requantise, store.  The (up to
   // three) tasks of a round run side by side without a branch between them: all window reads first, then three
   // independent chains of maxima and requantiser -- one wave per SIMD does this work, nothing else covers its latencies
+  int nst = 0;  // output stores this wave issued since its last patch request (they retire in order behind it)
   auto pool_rows = [&](auto pkc, int im, int ib, const StemStrip& e) {
     constexpr int PK = decltype(pkc)::value;
     int rm = ib + e.jm;  // ring slot of the row's first conv row: (ib + (j * ps) % RING) % RING
@@ -462,6 +472,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) __builtin_amdgcn_raw_buffer_store_b32(d[u] ^ p.xor_out, rsO, tk[u].st, orow, 0);
+        nst += UN;
         stamp(5);  // (pool pass: maxima, requantiser, stores)
       };
       round(tk0, oc0);
@@ -523,6 +534,11 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
 
   // running state: strip g - 1 (the rows to pool): strip, unit, ring base
   int t1 = 0, im1 = (int)blockIdx.x, ib1 = 0;
+  int tn = 1, imn = (int)blockIdx.x;  // the strip whose patch is requested next (strip 0's came with the multiplying waves' prologue)
+  if (tn == T) {
+    tn = 0;
+    imn += (int)gridDim.x;
+  }
   STEM_BAR();
 #if defined(I8IE_DIAG)
   if (p.dbg) tq = __builtin_amdgcn_s_memtime();
@@ -530,6 +546,14 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   for (int g = 0; g <= G; ++g) {
     // interval g: the multiplying waves work on strip g (none at g == G); here: the pooled rows completed by strip g - 1.
     // The output stores stay in flight across the barriers (STEM_BAR waits for LDS operations only).
+    if (STEM_DMA_VEC && g + 1 < G) {  // the patch of strip g + 1 -> the buffer strip g - 1 was read from
+      patch_dma(imn, strip(imn, tn), (g + 1) & 1);
+      if (++tn == T) {
+        tn = 0;
+        imn += (int)gridDim.x;
+      }
+      nst = 0;
+    }
     stamp(0);  // patch request
     if (g >= 1) {
       const StemStrip e = strip(im1, t1);
@@ -551,6 +575,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     }
     stamp(1);  // pool pass
     if constexpr (ACC) wait_vm_keep(0);
+    else if (STEM_DMA_VEC) wait_vm_keep(nst);  // the patch has landed; the stores issued behind it may stay in flight
     stamp(2);
     STEM_BAR();
     stamp(3);  // at the barrier
