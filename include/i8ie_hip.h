@@ -81,6 +81,10 @@ int i8ie_sync(i8ie_ctx* ctx);
  * (default 1 = all).  Event packets cost a few microseconds each on the stream; a stride that is
  * coprime with the launches per batch samples every kernel over a few batches. */
 #define I8IE_OPT_PROFILE_STRIDE 3
+/* I8IE_OPT_CU_LIMIT = 4: the compute units the ctx's stream may use, for a ctx created on a stream with a CU mask
+ * (hipExtStreamCreateWithCUMask + i8ie_ctx_create_on_stream): one-block-per-CU kernels size their grids and their
+ * work splits by min(device CUs, value).  0 (default) = all of the device's. */
+#define I8IE_OPT_CU_LIMIT 4
 int i8ie_ctx_set_option(i8ie_ctx* ctx, int option, int value);
 
 /* Activation layouts accepted by the *_fused / *_nhwc entry points.  NCHW is the

@@ -17,6 +17,7 @@ struct i8ie_ctx {
   void* pool = nullptr;  // I8iePool* (i8ie_ctx.hip): stream-ordered caching allocator
   void* prof = nullptr;  // I8ieProf* (i8ie_ctx.hip): HIP-event timing of every launch, when enabled
   unsigned options = 0;  // bit 0: I8IE_OPT_FORCE_FALLBACK
+  int cu_limit = 0;  // I8IE_OPT_CU_LIMIT: compute units of the stream's CU mask (0 = the whole device)
   int variant = 0;  // I8IE_OPT_KERNEL_VARIANT: selects among compiled kernel variants (A/B timing aid)
   int prof_mfma_only = 0;  // time only the contraction kernels (fewer event packets in a timed region)
   int prof_stride = 1;     // I8IE_OPT_PROFILE_STRIDE: bracket every prof_stride-th eligible launch
@@ -50,6 +51,8 @@ void i8ie_set_error(const char* fmt, ...);
 // I8IE_OPT_KERNEL_VARIANT values that name a Linear kernel (80, 81, 83) or a first-stage form (12, 13) leave the dispatch of the
 // OTHER convolutions automatic (round 3's advice: a variant changes the one thing it names; with 83 set process-wide the conv
 // layers used to lose the patch-stationary kernel their pools were planned for)
+// compute units a one-block-per-CU kernel may count on: the device's, or the ctx's CU-mask share
+inline int i8ie_cus(const i8ie_ctx* ctx, int device_cus) { return ctx->cu_limit > 0 && ctx->cu_limit < device_cus ? ctx->cu_limit : device_cus; }
 inline bool i8ie_conv_variant_auto(int v) { return v == 0 || v == 12 || v == 13 || v == 16 || v == 80 || v == 81 || v == 83; }
 
 #define I8IE_HIP_TRY(expr)                                                                  \

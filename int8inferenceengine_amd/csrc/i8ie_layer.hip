@@ -236,8 +236,13 @@ extern "C" {
 int i8ie_ctx_set_option(i8ie_ctx* ctx, int option, int value) {
   I8IE_REQUIRE(ctx != nullptr, "null ctx");
   I8IE_REQUIRE(option == I8IE_OPT_FORCE_FALLBACK || option == I8IE_OPT_KERNEL_VARIANT ||
-                   option == I8IE_OPT_PROFILE_STRIDE,
+                   option == I8IE_OPT_PROFILE_STRIDE || option == I8IE_OPT_CU_LIMIT,
                "unknown option");
+  if (option == I8IE_OPT_CU_LIMIT) {
+    I8IE_REQUIRE(value >= 0, "CU limit must be >= 0");
+    ctx->cu_limit = value;
+    return I8IE_OK;
+  }
   if (option == I8IE_OPT_PROFILE_STRIDE) {
     I8IE_REQUIRE(value >= 1, "profile stride must be >= 1");
     ctx->prof_stride = value;

@@ -512,7 +512,7 @@ static int pconv_impl(i8ie_ctx* ctx, const I8ieIgemmCall& c, bool dry) {
     I8IE_HIP_TRY(hipGetDeviceProperties(&props[dev], ctx->device));
     have[dev] = true;
   }
-  int grid = props[dev].multiProcessorCount / 8 * 8;
+  int grid = i8ie_cus(ctx, props[dev].multiProcessorCount) / 8 * 8;
   if (grid < 8) grid = 8;
   auto pick_rows = [&](int npass_, bool narrow_only) {
     int best_rt = 0;

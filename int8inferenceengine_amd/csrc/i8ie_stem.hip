@@ -724,7 +724,8 @@ int i8ie_stem_launch(i8ie_ctx* ctx, const I8ieStemCall& c) {
   // unit of its own; a part recomputes the pk - ps conv rows it shares with its neighbour (1 of 28 on AlexNet's conv1)
   StemPlan s;
   int parts = 1;
-  while (parts < 4 && (long)c.n * parts * 4 < (long)cus[dev] * 3) parts *= 2;
+  const int ncu = i8ie_cus(ctx, cus[dev]);
+  while (parts < 4 && (long)c.n * parts * 4 < (long)ncu * 3) parts *= 2;
   if (ctx->variant == 12) parts = 1;  // (I8IE_VARIANT_STEM_WHOLE)
   while (parts > 1 && !stem_plan(c.c, c.stride, c.N, c.KH, c.KW, c.OH, c.OW, c.pool_k, c.pool_s, parts, &s)) parts /= 2;
   if (!stem_plan(c.c, c.stride, c.N, c.KH, c.KW, c.OH, c.OW, c.pool_k, c.pool_s, parts, &s)) {
@@ -780,7 +781,7 @@ int i8ie_stem_launch(i8ie_ctx* ctx, const I8ieStemCall& c) {
   a.parts = s.parts;
   a.lg_parts = s.parts == 4 ? 2 : (s.parts == 2 ? 1 : 0);
   a.lds_adv = s.lds_adv;
-  int grid = cus[dev];
+  int grid = ncu;
   if (grid > c.n * s.parts) grid = c.n * s.parts;
   const double ops = 2.0 * c.n * c.OH * c.OW * (double)c.N * c.c * c.KH * c.KW;
   const double bytes = (double)c.n * img_pitch + (double)out_bytes;

@@ -493,7 +493,7 @@ int i8ie_tconv_try_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
     I8IE_HIP_TRY(hipGetDeviceProperties(&props[dev], ctx->device));
     have[dev] = true;
   }
-  int grid = props[dev].multiProcessorCount / 8 * 8;
+  int grid = i8ie_cus(ctx, props[dev].multiProcessorCount) / 8 * 8;
   if (grid < 8) grid = 8;
   // Chosen automatically only where it measured faster than i8ie_pconv.hip: one feature pass, whole patches in the
   // ring, and enough bands per CU to amortise the idle first / last segment of the two teams (AlexNet conv2 at

@@ -492,3 +492,38 @@ def test_gpu_contraction_against_the_reference_gemm_provider(gpu):
         assert np.array_equal(acc2, Cm - oc[None, :])
         n += 1
     assert n == 10
+
+
+def test_ctx_on_a_cu_masked_stream_with_a_cu_limit(orc):
+    """I8IE_OPT_CU_LIMIT: a ctx on a stream that may use 64 of the CUs (hipExtStreamCreateWithCUMask) sizes its one-block-per-CU
+    kernels for 64 CUs; conv (patch-stationary kernel, pool folded in) and the first-stage kernel stay bit-exact, and a negative
+    limit is an argument error."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    mask = (C.c_uint32 * 8)(0xFFFFFFFF, 0xFFFFFFFF, 0, 0, 0, 0, 0, 0)
+    stream = C.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(stream), C.c_uint32(8), mask) == 0
+    lib = abi.lib()
+    g = abi.Ctx.__new__(abi.Ctx)
+    g.h = C.c_void_p()
+    abi.ck(lib.i8ie_ctx_create_on_stream(0, stream, C.byref(g.h)))
+    try:
+        assert lib.i8ie_ctx_set_option(g.h, 4, -1) != 0
+        abi.ck(lib.i8ie_ctx_set_option(g.h, 4, 64))
+        cs = synth.conv_case(orc, 77, 300, 96, 27, 27, 256, 5, 1, 2)
+        names = []
+        out, acc = g.layer_forward_pool(cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"], cs["s_out"], cs["zp_out"],
+                                        stride=1, pad=2, in_nhwc=True, out_nhwc=True, relu=True, in_border=2, pool=(3, 2), names=names)
+        assert any(nm.startswith("pconv_pool") for nm in names), names
+        assert np.array_equal(acc, cs["acc"])
+        assert np.array_equal(out, orc.max_pool2d(orc.relu(cs["out"], cs["zp_out"]), 3, 2))
+        cs = synth.conv_case(orc, 78, 150, 3, 67, 83, 64, 7, 4, 3)
+        names = []
+        out, acc = g.layer_forward_pool(cs["q_in"], cs["qw"], cs["qb"], cs["s_in"], cs["zp_in"], cs["s_w"], cs["s_out"], cs["zp_out"],
+                                        stride=4, pad=3, out_nhwc=True, relu=True, out_border=1, pool=(3, 2), names=names)
+        assert "stem_conv_pool" in names, names
+        assert np.array_equal(acc, cs["acc"])
+        assert np.array_equal(out, orc.max_pool2d(orc.relu(cs["out"], cs["zp_out"]), 3, 2))
+    finally:
+        g.close()
+        hip.hipStreamDestroy(stream)
