@@ -53,7 +53,12 @@ constexpr int kMlStages = 4;
 constexpr int kMlLds = kMlStages * kMlStage;
 constexpr int kMlPieces = kMlStage / 1024;  // 32 DMA pieces per chunk: 8 rows of 128 bytes each
 constexpr int kMlPPW = kMlPieces / 4;       // per loader wave
-constexpr int kMlAhead = 10;                // a line is touched (-> L2) this many chunks before the chunk being multiplied
+// (A/B builds, tools/dbg/build_ab.sh i8ie_mlin wt-DML_AHEAD=<n> / wt-DML_NO_TOUCH=1; fc6 + fc7 inside the AlexNet step: 10 chunks ahead
+//  0.0828 ms, 4: 0.0800, 2: 0.0826, no touches at all 0.0818; 20: slower)
+#if !defined(ML_AHEAD)
+#define ML_AHEAD 4
+#endif
+constexpr int kMlAhead = ML_AHEAD;                // a line is touched (-> L2) this many chunks before the chunk being multiplied
 
 template <int N>
 __device__ __forceinline__ void ml_wait_vm() {
@@ -169,6 +174,9 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
                               ? (wave == 0 ? (unsigned)(n0 + t_row) * (unsigned)p.Kpad : (unsigned)t_row * p.lda) + (unsigned)t_ch * kMlChunk
                               : 0xFFFFFF00u;
   auto touch = [&](int ch) {  // chunks ch .. ch + cpi - 1 (past the end of K: the next row's bytes, harmless; beyond the buffer: dropped)
+#if defined(ML_NO_TOUCH)
+    return;
+#endif
     if (wave > 1 || ch >= nch) return;
     const unsigned off = t_base == 0xFFFFFF00u ? t_base : t_base + (unsigned)ch * kMlChunk;
     // (destination: v255, named as a clobber and otherwise unused -- the kernel needs ~220 registers; a compiler-visible output
