@@ -39,6 +39,11 @@
 #define STEM_DMA_VEC 0
 #endif
 
+#if defined(STEM_PRIO_SWAP)  // (A/B: the multiplying waves raised instead of the vector waves)
+#define STEM_VPRIO 0
+#define STEM_MPRIO 3
+#endif
+
 namespace {
 
 // exact quantize: t = x / scale + zp (fp32 divide, fp32 add), q = ((int)t) & 0xFF (src/quantize_utils.cc:49).
@@ -203,6 +208,9 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
 #endif
 
   if (wave < 4) {
+#if defined(STEM_MPRIO)
+    __builtin_amdgcn_s_setprio(STEM_MPRIO);
+#endif
     // =========================== multiplying waves ==========================================================
     constexpr int NA = NG - 1;  // groups of pass A (weights in registers); the last group's come from LDS
     v4i breg[NA > 0 ? NA : 1][KS];
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         // A's finished accumulators to the INT32 ring (lane = pixel, register group q = features 8 q + 4 hh .. + 3):
         // the LDS store path takes ~13 cycles per wave-instruction for the whole CU (MI355X guide, LDS), four waves
         // storing 12 of them each at the same moment held every MFMA pipe for ~800 cycles per strip (phase stamps).
-        constexpr int DEPTH = KS < 4 ? KS : 4;
+        constexpr int DEPTH = KS < 4 ? KS : 4;  // (3 or 6 ahead: the same time; pass B 4 ahead the same, 8 spills)
         v16i acc[NG];
         const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint8_t* const wbase = valid ? rbase : smem + p.lds_dump + lane * 16;  // (lanes past the strip store into a 2 KiB dump)
@@ -357,11 +365,15 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   // =============================== vector waves ==============================================================
   const int vt = (wave - 4) * 64 + lane;  // 0 .. 255
   const int vwave = wave - 4;
-  // the vector waves are the younger half of the block: at equal priority they get what issue slots the multiplying
-  // waves leave (MI355X guide, "two waves per SIMD": +7 % here with the vector waves raised)
-  __builtin_amdgcn_s_setprio(3);
+  // Wave priority: in round 3 the vector waves (330 instructions a round, the critical path) ran 7 % faster raised to priority 3.
+  // With the round-4 pool pass (210 instructions) the multiplying waves are the critical path and a raised vector role costs:
+  // first stage inside the AlexNet step 0.1833 ms at priority 3, 0.183 at 1, 0.1727 at 0 (tools/dbg/run_step_ab.sh) -- equal priority.
+#if !defined(STEM_VPRIO)
+#define STEM_VPRIO 0
+#endif
+  if (STEM_VPRIO) __builtin_amdgcn_s_setprio(STEM_VPRIO);
 #if defined(I8IE_DIAG)
-  if (p.dbg_flags & 1) __builtin_amdgcn_s_setprio(0);  // experiment: no priority
+  if (p.dbg_flags & 1) __builtin_amdgcn_s_setprio(3);  // experiment: the vector waves raised
 #endif
   const I8ieRequant rq = p.rq;
   const int lo_relu = p.relu_lo;
@@ -390,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   // A wave's pool tasks: k = vwave + 4 u (+ 12 per further round); task k = (pixel octet po, quad octet qo).  What does
   // not depend on the pooled row is worked out once: LDS offset of the lane's window origin, output offset (lanes past
   // the row's last pixel: read pixel 0 of the task, store beyond the descriptor's range), LDS address of its oc' quad
-  constexpr int UN = 3;
+  constexpr int UN = 3;  // (2: 0.216 ms, 1: 0.193 ms against 0.176 inside the AlexNet step)
   struct PoolTask {
     int rd, st, oc;
   };
