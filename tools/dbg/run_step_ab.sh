@@ -12,7 +12,7 @@ for i in 1 2; do
 import json
 d=json.loads(open("gpurun_out/$tag/bench_$n.json").read().strip().splitlines()[-1])
 k=d["kernel_ms_per_step"]
-print("$n", d["value"], d["ms_per_step"], {x:k[x] for x in k if "lin" in x or "stem" in x})
+print("$n", d["value"], d["ms_per_step"], {x:k[x] for x in k if "lin" in x or "stem" in x or "quant" in x})
 PY
   done
 done
