@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
 
   for (int i = tid; i < p.N; i += 512) reinterpret_cast<int*>(smem + p.lds_ocp)[i] = p.ocp[i];
   // weights of the LAST feature group, in MFMA fragment order [k-step][lane][16 B]: the multiplying waves read them from
-  // here (pass B below) instead of holding them in registers: 4 x KS registers that the first NG - 1 groups' weights,
+  // here (one fragment per k-step) instead of holding them in registers: 4 x KS registers that the first NG - 1 groups' weights,
   // the accumulators and the fragment rings need (256 per wave at two waves per SIMD)
   for (int i = tid; i < KS * 64; i += 512) {
     const int j = i >> 6, ln = i & 63;
@@ -273,12 +273,12 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         int ls = slot + lr;
         if (ls >= RING) ls -= RING;
         uint8_t* const rbase = smem + p.lds_ring + ls * p.ringRowB + roff;
-        // Two passes over K.  Pass A: feature groups 0 .. NG-2, k-step by k-step (one fragment read feeds NG-1 MFMAs).
-        // Pass B: the last group alone, the fragments read again -- and between its MFMAs the ds_write_b128 that move pass
-        // A's finished accumulators to the INT32 ring (lane = pixel, register group q = features 8 q + 4 hh .. + 3):
-        // the LDS store path takes ~13 cycles per wave-instruction for the whole CU (MI355X guide, LDS), four waves
-        // storing 12 of them each at the same moment held every MFMA pipe for ~800 cycles per strip (phase stamps).
-        constexpr int DEPTH = KS < 4 ? KS : 4;  // (3 or 6 ahead: the same time; pass B 4 ahead the same, 8 spills)
+        // One pass over K: a k-step is NG MFMAs on one fragment read (the first NG - 1 groups' weights from registers, the last
+        // group's fragments from LDS), reads four k-steps ahead, the 4 NG ring stores (lane = pixel, register group q = features
+        // 8 q + 4 hh .. + 3) behind the last MFMA.  Until late in round 4 this was two passes (groups 0 .. NG-2, then the last
+        // group alone with pass A's ds_write_b128 spread between its MFMAs: with the round-3 vector role, four waves storing 12
+        // each at the same moment held every MFMA pipe for ~800 cycles per strip); with the lighter vector role and equal wave
+        // priority the one-pass form is the faster one: 0.1723 -> 0.1686 ms inside the AlexNet step (tools/dbg/run_step_ab.sh).
         v16i acc[NG];
         const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint8_t* const wbase = valid ? rbase : smem + p.lds_dump + lane * 16;  // (lanes past the strip store into a 2 KiB dump)
@@ -288,28 +288,8 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
           v.x = acc[gg][q * 4 + 0]; v.y = acc[gg][q * 4 + 1]; v.z = acc[gg][q * 4 + 2]; v.w = acc[gg][q * 4 + 3];
           *reinterpret_cast<v4i*>(wbase + (gg * 32 + 8 * q) * 4) = v;
         };
-        if constexpr (NA > 0) {
-          v4i ring[DEPTH];
-          static_for<0, DEPTH>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            ring[j] = *reinterpret_cast<const v4i*>(abase + koff[j]);
-          });
-          __builtin_amdgcn_sched_barrier(0);
-          static_for<0, KS>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const v4i af = ring[j % DEPTH];
-            if constexpr (j + DEPTH < KS) {
-              ring[j % DEPTH] = *reinterpret_cast<const v4i*>(abase + koff[j + DEPTH]);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int gg = 0; gg < NA; ++gg) acc[gg] = __builtin_amdgcn_mfma_i32_32x32x32_i8(breg[gg][j], af, j == 0 ? z : acc[gg], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        }
-        {
-          // (one MFMA per k-step here: 32 cycles a step, an LDS round trip is 150-200 under load -- the reads run six ahead)
-          constexpr int DB = KS < 6 ? KS : 6;
+        {  // one pass over K: a k-step is NG MFMAs (the first NG - 1 groups' weights from registers, the last group's from LDS)
+          constexpr int DB = KS < 4 ? KS : 4;
           v4i ring[DB], bring[DB];
           const uint8_t* const bbase = smem + p.lds_bfrag + lane * 16;
           static_for<0, DB>([&](auto jc) {
@@ -326,19 +306,15 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
               bring[j % DB] = *reinterpret_cast<const v4i*>(bbase + (j + DB) * 1024);
               __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int gg = 0; gg < NA; ++gg) acc[gg] = __builtin_amdgcn_mfma_i32_32x32x32_i8(breg[gg][j], af, j == 0 ? z : acc[gg], 0, 0, 0);
             acc[NG - 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf, af, j == 0 ? z : acc[NG - 1], 0, 0, 0);
-            // pass A's stores, spread over the steps of pass B from the second one on
-            if constexpr (NA > 0 && j >= 1) {
-              constexpr int per = (4 * NA + (KS - 1) - 1) / (KS - 1);  // stores per step
-              static_for<0, per>([&](auto wc) {
-                constexpr int idx = (j - 1) * per + decltype(wc)::value;
-                if constexpr (idx < 4 * NA) ring_store(std::integral_constant<int, idx / 4>{}, std::integral_constant<int, idx % 4>{});
-              });
-            }
             __builtin_amdgcn_sched_barrier(0);
           });
+          if constexpr (NA > 0)
+            static_for<0, 4 * NA>([&](auto ic) { ring_store(std::integral_constant<int, decltype(ic)::value / 4>{}, std::integral_constant<int, decltype(ic)::value % 4>{}); });
         }
-        stamp(0);  // addresses, fragment reads, MFMAs (+ pass A's ring stores)
+        stamp(0);  // addresses, fragment reads, MFMAs (+ the first NG - 1 groups' ring stores)
         static_for<0, 4>([&](auto qc) { ring_store(std::integral_constant<int, NG - 1>{}, qc); });
 #if defined(I8IE_DIAG)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
