@@ -165,15 +165,25 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
   }
   stem_fill_tables(p, smem, tid, T, RING);
   __syncthreads();  // (every wave, before the roles part: the tables are read from here on)
-  auto strip = [&](int unit, int t) {  // (wave-uniform: the entry lands in SGPRs)
+  // a table entry in two steps: the LDS reads (issued an interval early, in front of the barrier the wave waits at anyway) and
+  // the move to SGPRs -- a lookup in one piece exposes an LDS round trip under load to the wave's critical path, once per strip
+  auto strip_fetch = [&](int unit, int t, v4i& a, v4i& b) {
     const int idx = (unit & pmask) * T + t;
-    const v4i a = *reinterpret_cast<const v4i*>(smem + p.lds_tab + idx * 32), b = *reinterpret_cast<const v4i*>(smem + p.lds_tab + idx * 32 + 16);
+    a = *reinterpret_cast<const v4i*>(smem + p.lds_tab + idx * 32);
+    b = *reinterpret_cast<const v4i*>(smem + p.lds_tab + idx * 32 + 16);
+  };
+  auto strip_decode = [&](const v4i& a, const v4i& b) {  // (wave-uniform: the entry lands in SGPRs)
     StemStrip e;
     e.lo = __builtin_amdgcn_readfirstlane(a.x); e.hi = __builtin_amdgcn_readfirstlane(a.y);
     e.poff = __builtin_amdgcn_readfirstlane(a.z); e.pbytes = __builtin_amdgcn_readfirstlane(a.w);
     e.j0 = __builtin_amdgcn_readfirstlane(b.x); e.j1 = __builtin_amdgcn_readfirstlane(b.y);
     e.lom = __builtin_amdgcn_readfirstlane(b.z); e.jm = __builtin_amdgcn_readfirstlane(b.w);
     return e;
+  };
+  auto strip = [&](int unit, int t) {
+    v4i a, b;
+    strip_fetch(unit, t, a, b);
+    return strip_decode(a, b);
   };
   // patch of strip t of image im -> patch buffer pb: one contiguous run of the s2d image, whole 1 KiB LDS-DMA pieces, dealt
   // to the four waves of a role (w4 = wave & 3).  The MULTIPLYING waves issue them (first thing in an interval, for the
@@ -252,6 +262,8 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
                                    // its patch is requested, an interval ahead)
     patch_dma(imn, e, 0);
     next_n();
+    v4i fa, fb;  // the entry of the strip after: fetched in front of every barrier, decoded behind it
+    strip_fetch(imn, tn, fa, fb);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STEM_BAR();  // (the first patch)
 #if defined(I8IE_DIAG)
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     for (int g = 0; g < G; ++g) {
       StemStrip en{};
       if (g + 1 < G) {  // the patch of strip g + 1 -> the other buffer (strip g - 1 was its last reader)
-        en = strip(imn, tn);
+        en = strip_decode(fa, fb);
         if (!STEM_DMA_VEC) patch_dma(imn, en, pbuf ^ 1);
         next_n();
       }
@@ -321,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         stamp(1);  // ring writes
 #endif
       }
+      strip_fetch(imn, tn, fa, fb);
       if (!STEM_DMA_VEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the patch requested at the top of the interval has landed
       STEM_BAR();
       stamp(2);  // at the barrier
@@ -527,6 +540,8 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     tn = 0;
     imn += (int)gridDim.x;
   }
+  v4i fa, fb;  // the entry of the strip pooled in the next interval: fetched in front of every barrier, decoded behind it
+  strip_fetch(im1, t1, fa, fb);
   STEM_BAR();
 #if defined(I8IE_DIAG)
   if (p.dbg) tq = __builtin_amdgcn_s_memtime();
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
     }
     stamp(0);  // patch request
     if (g >= 1) {
-      const StemStrip e = strip(im1, t1);
+      const StemStrip e = strip_decode(fa, fb);
       const int img = im1 >> p.lg_parts;
       if (e.j1 > e.j0) {
         if (p.pk == 3) pool_rows(std::integral_constant<int, 3>{}, img, ib1, e);
@@ -561,6 +576,7 @@ __global__ __launch_bounds__(512, 2) void stem_conv_kernel(StemArgs p) {
         im1 += (int)gridDim.x;
       }
     }
+    strip_fetch(im1, t1, fa, fb);
     stamp(1);  // pool pass
     if constexpr (ACC) wait_vm_keep(0);
     else if (STEM_DMA_VEC) wait_vm_keep(nst);  // the patch has landed; the stores issued behind it may stay in flight
