@@ -76,6 +76,8 @@ int i8ie_sync(i8ie_ctx* ctx);
 #define I8IE_VARIANT_TCONV 70          /* two-team patch-stationary conv kernel (csrc/i8ie_tconv.hip) wherever its shape rules allow */
 #define I8IE_VARIANT_FLIN 80           /* few-row Linear kernel (csrc/i8ie_flin.hip) below its automatic feature threshold */
 #define I8IE_VARIANT_MLIN 83           /* many-row Linear kernel (csrc/i8ie_mlin.hip) from 257 rows on and below its automatic feature threshold */
+#define I8IE_VARIANT_MLIN_64 84        /* many-row Linear kernel with 64-row block tiles (automatic where 128-row tiles give at most half the CUs a block) */
+#define I8IE_VARIANT_MLIN_128 85       /* many-row Linear kernel with 128-row block tiles at any row count above 256 */
 #define I8IE_VARIANT_FLIN_128 81       /* few-row Linear kernel in its 128-row x 16-feature form at up to 128 rows (default above 64 rows: 64 x 32) */
 /* I8IE_OPT_PROFILE_STRIDE = 3: while profiling, bracket only every value-th eligible launch
  * (default 1 = all).  Event packets cost a few microseconds each on the stream; a stride that is

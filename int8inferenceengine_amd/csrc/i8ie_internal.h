@@ -53,7 +53,7 @@ void i8ie_set_error(const char* fmt, ...);
 // layers used to lose the patch-stationary kernel their pools were planned for)
 // compute units a one-block-per-CU kernel may count on: the device's, or the ctx's CU-mask share
 inline int i8ie_cus(const i8ie_ctx* ctx, int device_cus) { return ctx->cu_limit > 0 && ctx->cu_limit < device_cus ? ctx->cu_limit : device_cus; }
-inline bool i8ie_conv_variant_auto(int v) { return v == 0 || v == 12 || v == 13 || v == 16 || v == 80 || v == 81 || v == 83; }
+inline bool i8ie_conv_variant_auto(int v) { return v == 0 || v == 12 || v == 13 || v == 16 || v == 80 || v == 81 || v == 83 || v == 84 || v == 85; }
 
 #define I8IE_HIP_TRY(expr)                                                                  \
   do {                                                                                      \

@@ -630,7 +630,7 @@ static int layer_forward_impl(i8ie_layer* L, const uint8_t* in, int in_layout, i
 #endif
     // many rows: the one-launch kernel of i8ie_mlin.hip (variants 3 / 11 keep the tiled kernel, for comparison)
     const bool mlin = !need_pad && !flin && !lgemm && ctx->variant != 11 && ctx->variant != 3 && L->K % 16 == 0 && aligned16(out) &&
-                      L->Npad % 128 == 0 && i8ie_mlin_wants(m, L->n, L->Kpad, ctx->variant == 83);
+                      L->Npad % 128 == 0 && i8ie_mlin_wants(m, L->n, L->Kpad, ctx->variant == 83 || ctx->variant == 84 || ctx->variant == 85);
     if (blocks_est < 256 && nk >= 4 && !flin && !lgemm && !mlin) {
       ksplit = (int)((512 + blocks_est - 1) / blocks_est);
       if (ksplit > 8) ksplit = 8;

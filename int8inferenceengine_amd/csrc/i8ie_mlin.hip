@@ -1,5 +1,5 @@
 // i8ie_mlin.hip -- Linear::forward_prop(Tensor<u8_t>&&) (src/fully_connected.cc:22-52) for MANY input rows (> 256): fc6 / fc7 of a
-// 500 - 1000-image batch, in one launch without partial sums.
+// 257 - 1000-image batch, in one launch without partial sums.
 //
 //   C[r][j] = sum_k A_u8[r][k] * W_s8[j][k] + oc[j];  C += (int)bias;  out = relu?(down_scale(C))
 //
@@ -18,6 +18,8 @@
 //   * Blocks that share weights share an XCD (the 8 row tiles of a 128-feature tile walk K in step: the weights cross the fabric
 //     once, 37.7 MB for fc6, the activations once per XCD).
 //   * Epilogue of src/fully_connected.cc:42-48 from the 64 accumulator registers: + oc', float bias, down_scale, ReLU.
+//   * A second instantiation with 64-row block tiles (24 KiB per chunk, multiplying waves of 32 rows x 64 features) runs where the
+//     128-row tiles would leave half the CUs without a block: 257-512 rows of fc6 / fc7 (the 500-image shard of a 2-GPU run).
 #include "i8ie_calls.h"
 #include "i8ie_internal.h"
 #include "i8ie_requant.h"
@@ -47,12 +49,20 @@ struct MlinArgs {
 };
 
 constexpr int kMlChunk = 128;                 // K bytes per chunk
-constexpr int kMlRows = 128, kMlFeats = 128;  // block tile
-constexpr int kMlStage = (kMlRows + kMlFeats) * kMlChunk;  // 32 KiB
+constexpr int kMlFeats = 128;                 // features of a block tile
 constexpr int kMlStages = 4;
-constexpr int kMlLds = kMlStages * kMlStage;
-constexpr int kMlPieces = kMlStage / 1024;  // 32 DMA pieces per chunk: 8 rows of 128 bytes each
-constexpr int kMlPPW = kMlPieces / 4;       // per loader wave
+// RB: rows of a block tile, 128 or -- when 128-row tiles would leave half the CUs without a block (the 500-row shard: 4 x 32 tiles
+// for fc6) -- 64: twice the blocks, 24 KiB of operands per chunk for half the MFMAs (the kernel is bound by what a CU's
+// vector-memory path delivers, 27 B/clk: 0.45 us per chunk instead of 0.6)
+template <int RB>
+struct MlShape {
+  static constexpr int kRows = RB;
+  static constexpr int kStage = (RB + kMlFeats) * kMlChunk;  // 32 / 24 KiB
+  static constexpr int kLds = kMlStages * kStage;
+  static constexpr int kPA = RB / 32, kPB = kMlFeats / 32;   // DMA pieces (8 rows of 128 bytes) per loader wave and chunk: A's, B's
+  static constexpr int kPPW = kPA + kPB;
+  static constexpr int kIT = RB / 32;                         // 16-row MFMA tiles per multiplying wave (2 x 2 waves)
+};
 // (A/B builds, tools/dbg/build_ab.sh i8ie_mlin wt-DML_AHEAD=<n> / wt-DML_NO_TOUCH=1; fc6 + fc7 inside the AlexNet step: 10 chunks ahead
 //  0.0828 ms, 4: 0.0800, 2: 0.0826, no touches at all 0.0818; 20: slower)
 #if !defined(ML_AHEAD)
@@ -66,7 +76,10 @@ __device__ __forceinline__ void ml_wait_vm() {
 }
 #define ML_BAR() asm volatile("s_barrier" ::: "memory")
 
+template <int RB>
 __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
+  using S = MlShape<RB>;
+  constexpr int kMlRows = S::kRows, kMlStage = S::kStage, kMlPPW = S::kPPW, IT = S::kIT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,26 +98,27 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.A + a_off), 0,
                                                                          (unsigned)(a_left < 0xFFFFF000u ? a_left : 0xFFFFF000u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.B), 0, p.b_bytes, 0x00020000);
-    // piece pi = lw + 4 jj: rows 8 pi' .. 8 pi' + 7 of A (pi < 16) or of the block's weight rows (pi >= 16); lane l: row
-    // 8 pi' + (l >> 3), LDS slot l & 7, source slot (l & 7) ^ ((row >> 1) & 7)
+    // this wave's pieces of a chunk: A's lw + 4 jj (jj < kPA: rows 8 pi .. 8 pi + 7 of the block's RB activation rows), then B's
+    // lw + 4 jj' (jj' < kPB: of its 128 weight rows, behind A's RB rows in the stage); lane l: row 8 pi + (l >> 3), LDS slot l & 7,
+    // source slot (l & 7) ^ ((row >> 1) & 7)
     unsigned src[kMlPPW];
 #pragma unroll
     for (int jj = 0; jj < kMlPPW; ++jj) {
-      const int pi = lw + 4 * jj;
-      const int row = 8 * (pi & 15) + (lane >> 3);
+      const bool isA = jj < S::kPA;
+      const int pi = lw + 4 * (isA ? jj : jj - S::kPA);
+      const int row = 8 * pi + (lane >> 3);
       const unsigned slot = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
-      src[jj] = pi < 16 ? (unsigned)row * p.lda + slot : (unsigned)(n0 + row) * (unsigned)p.Kpad + slot;
+      src[jj] = isA ? (unsigned)row * p.lda + slot : (unsigned)(n0 + row) * (unsigned)p.Kpad + slot;
     }
     auto issue = [&](int ch) {  // chunk ch -> stage ch % 4
       const unsigned k = (unsigned)ch * kMlChunk;
       uint8_t* st = smem + (ch & (kMlStages - 1)) * kMlStage;
 #pragma unroll
       for (int jj = 0; jj < kMlPPW; ++jj) {
-        const int pi = lw + 4 * jj;
-        if (jj < kMlPPW / 2)  // (pieces lw, lw + 4, lw + 8, lw + 12 are A's; the other four B's)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + pi * 1024), 16, (int)(src[jj] + k), 0, 0, 0);
+        if (jj < S::kPA)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (lw + 4 * jj) * 1024), 16, (int)(src[jj] + k), 0, 0, 0);
         else
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + pi * 1024), 16, (int)(src[jj] + k), 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + kMlRows * kMlChunk + (lw + 4 * (jj - S::kPA)) * 1024), 16, (int)(src[jj] + k), 0, 0, 0);
       }
     };
     // wait until chunk c has landed, given that chunks up to `last` have been issued (this wave's pieces retire in order)
@@ -142,15 +156,15 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
   // gets a slot per MFMA (first build, 32 x 32: 0.8 us per chunk, the loaders could not issue their eight DMA pieces).
   const int wr = wave >> 1, wf = wave & 1;
   const int lq = lane >> 4, lr = lane & 15;
-  // fragment addresses inside a stage: A row 64 wr + 16 i + lr, B feature row 64 wf + 16 n + lr; k-step ks (64 bytes of K) =
+  // fragment addresses inside a stage: A row 16 IT wr + 16 i + lr, B feature row 64 wf + 16 n + lr; k-step ks (64 bytes of K) =
   // logical slots 4 ks + lq, physical slot = logical ^ ((row >> 1) & 7)
-  int aoff[4][2], boff[4][2];  // stage-relative byte offsets of this lane's fragments
+  int aoff[IT][2], boff[4][2];  // stage-relative byte offsets of this lane's fragments
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int ar = 64 * wr + 16 * i + lr, br = 64 * wf + 16 * i + lr;
+    const int ar = 16 * IT * wr + 16 * i + lr, br = 64 * wf + 16 * i + lr;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      aoff[i][ks] = ar * kMlChunk + (((4 * ks + lq) ^ ((ar >> 1) & 7)) * 16);
+      if (i < IT) aoff[i][ks] = ar * kMlChunk + (((4 * ks + lq) ^ ((ar >> 1) & 7)) * 16);
       boff[i][ks] = kMlRows * kMlChunk + br * kMlChunk + (((4 * ks + lq) ^ ((br >> 1) & 7)) * 16);
     }
   }
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
   const int rpt = wave == 0 ? rpb : rpa;
   const int cpi = 64 / rpt;  // chunks per touch instruction (this wave's)
   const int t_row = (wave == 0 ? mt * rpb : (j / p.m_tiles) * rpa) + lane % rpt, t_ch = lane / rpt;
-  const unsigned t_base = (t_row < 128 && t_ch < cpi)
+  const unsigned t_base = (t_row < (wave == 0 ? kMlFeats : kMlRows) && t_ch < cpi)
                               ? (wave == 0 ? (unsigned)(n0 + t_row) * (unsigned)p.Kpad : (unsigned)t_row * p.lda) + (unsigned)t_ch * kMlChunk
                               : 0xFFFFFF00u;
   auto touch = [&](int ch) {  // chunks ch .. ch + cpi - 1 (past the end of K: the next row's bytes, harmless; beyond the buffer: dropped)
@@ -187,27 +201,27 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
   };
   for (int c = kMlStages; c < p.ahead + cpi; c += cpi) touch(c);
   int touch_in = 1;
-  v4i acc[4][4];
+  v4i acc[IT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < IT; ++i)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[i][n] = v4i{0, 0, 0, 0};
-  v4i FA0[4][2], FB0[4][2], FA1[4][2], FB1[4][2];
-  auto read_chunk = [&](v4i (&fa)[4][2], v4i (&fb)[4][2], int ch) {
+  v4i FA0[IT][2], FB0[4][2], FA1[IT][2], FB1[4][2];
+  auto read_chunk = [&](v4i (&fa)[IT][2], v4i (&fb)[4][2], int ch) {
     const uint8_t* st = smem + (ch & (kMlStages - 1)) * kMlStage;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i][ks] = *reinterpret_cast<const v4i*>(st + aoff[i][ks]);
+        if (i < IT) fa[i][ks] = *reinterpret_cast<const v4i*>(st + aoff[i][ks]);
         fb[i][ks] = *reinterpret_cast<const v4i*>(st + boff[i][ks]);
       }
   };
-  auto mfma_chunk = [&](const v4i (&fa)[4][2], const v4i (&fb)[4][2]) {
+  auto mfma_chunk = [&](const v4i (&fa)[IT][2], const v4i (&fb)[4][2]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < IT; ++i) {
         const v4i a = fa[i][ks] ^ (int)0x80808080;  // u8 -> s8 (128 * wsum is in ocp).  (Re-biasing in LDS by the loader lanes that
                                                     // fetched the bytes was tried: 56 -> 68 us, the pass sits in the barrier's path)
 #pragma unroll
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
   };
   // one chunk's 32 MFMAs with the next chunk's 16 fragment reads spread between them.  (Tied asm MFMAs with the reads fenced
   // between them gave a tidier stream -- no accumulator moves -- and the same time, 53 us for fc6: the step is not what bounds it)
-  auto step = [&](const v4i (&fa)[4][2], const v4i (&fb)[4][2], v4i (&na)[4][2], v4i (&nb)[4][2], int next_ch) {
+  auto step = [&](const v4i (&fa)[IT][2], const v4i (&fb)[4][2], v4i (&na)[IT][2], v4i (&nb)[4][2], int next_ch) {
     if (--touch_in == 0) {  // (every cpi chunks; a countdown: `% cpi` with a run-time cpi cost ~300 cycles of every chunk)
       touch_in = cpi;
       touch(next_ch - 1 + p.ahead);
@@ -224,10 +238,10 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
     read_chunk(na, nb, next_ch);
     mfma_chunk(fa, fb);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // 2 VALU (the re-bias xor)
+    for (int q = 0; q < 4 * IT; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                // 2 MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, IT == 4 ? 1 : 2, 0);  // 1 DS read (of 16; 64-row tiles: of 12 over 8 groups)
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                // 2 VALU (the re-bias xor)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next chunk's fragments are in registers: its stage may be refilled
     ML_BAR();
@@ -249,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "v255", "memory");  // (the touches have landed long ago; nothing may land after the wave is gone)
-  // ---- epilogue of src/fully_connected.cc:42-48: lane (lq, lr) holds row 64 wr + 16 i + lr and features 64 wf + 16 n + 4 lq .. + 3
+  // ---- epilogue of src/fully_connected.cc:42-48: lane (lq, lr) holds row 16 IT wr + 16 i + lr and features 64 wf + 16 n + 4 lq .. + 3
   //      oc' and the float bias of this lane's 16 features come as eight 16-byte loads issued together (the first build read them
   //      one dword at a time inside the tile loop: 128 dependent round trips, 20 us of a 60 us kernel)
   const I8ieRequant rq = p.rq;
@@ -279,8 +293,8 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = row0 + 64 * wr + 16 * i + lr;
+  for (int i = 0; i < IT; ++i) {
+    const int row = row0 + 16 * IT * wr + 16 * i + lr;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const int f = n0 + 64 * wf + 16 * n + 4 * lq;
@@ -311,13 +325,33 @@ __global__ __launch_bounds__(512, 2) void mlin_kernel(MlinArgs p) {
 
 }  // namespace
 
-// more rows than the few-row kernel takes, a whole number of 128-byte chunks of K, and enough of them for the four-stage ring
-// (automatic from 4 row tiles on.  On their own -- weights still in the Infinity Cache from the launch before -- the tiled kernel's
-// finer tiles are as fast at 500 rows (fc6 + fc7 73.5 against 71.5 us); INSIDE the AlexNet step, where the weights come from HBM
-// every time, this kernel's touches pay: 0.075 against 0.096 ms at 500 rows, the step 0.713 against 0.747 ms.  At 384 rows (96
-// blocks) the tiled kernel + split-K wins, 0.079 against 0.083.  `force`, kernel variant 83, lifts the thresholds for tests)
+// more rows than the few-row kernel takes (256), a whole number of 128-byte chunks of K, and enough of them for the four-stage ring.
+// With the 64-row tile this kernel wins from 257 rows on (fc6 + fc7 alone, us: 257 rows 45 against 63 tiled + split-K, 384 rows 46
+// against 68, 500 rows 52 against 74; 128-row tiles from 513 rows: 640 rows 69, 1000 rows 80 against 98); inside the AlexNet step,
+// where the weights come from HBM every time, 0.053 against 0.096 ms at 500 rows.  `force` (kernel variants 83-85) lifts the feature
+// threshold for tests.
 bool i8ie_mlin_wants(int m, int n, int Kpad, bool force) {
-  return m > 256 && (force || (m > 384 && n >= 2048)) && Kpad % kMlChunk == 0 && Kpad >= 4 * kMlChunk;
+  return m > 256 && (force || n >= 2048) && Kpad % kMlChunk == 0 && Kpad >= 4 * kMlChunk;
+}
+
+template <int RB>
+static int mlin_launch_t(i8ie_ctx* ctx, MlinArgs& a, const I8ieIgemmCall& c, const char* name) {
+  using S = MlShape<RB>;
+  I8IE_REQUIRE((size_t)RB * c.lda + c.Kpad < ((size_t)1 << 31), "mlin: offsets exceed 32 bits");
+  a.m_tiles = (c.M + RB - 1) / RB;
+  static bool raised[64] = {};
+  const int dev = ctx->device & 63;
+  if (!raised[dev]) {
+    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlin_kernel<RB>), hipFuncAttributeMaxDynamicSharedMemorySize, S::kLds));
+    raised[dev] = true;
+  }
+  const int per = (a.n_tiles + 7) / 8;
+  const int grid = 8 * per * a.m_tiles;
+  const double ops = 2.0 * c.M * c.N * c.Ktrue, bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
+  I8ieProfScope prof(ctx, name, ops, bytes);
+  mlin_kernel<RB><<<grid, 512, S::kLds, ctx->stream>>>(a);
+  I8IE_LAUNCH_CHECK();
+  return I8IE_OK;
 }
 
 int i8ie_mlin_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
@@ -325,7 +359,7 @@ int i8ie_mlin_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   I8IE_REQUIRE((reinterpret_cast<uintptr_t>(c.A) & 15u) == 0 && (reinterpret_cast<uintptr_t>(c.B) & 15u) == 0 && c.lda % 16 == 0 &&
                    (reinterpret_cast<uintptr_t>(c.out) & 15u) == 0,
                "mlin: operands must be 16-byte aligned");
-  I8IE_REQUIRE((size_t)c.Npad * c.Kpad < ((size_t)1 << 32) - 4096 && (size_t)kMlRows * c.lda + c.Kpad < ((size_t)1 << 31), "mlin: offsets exceed 32 bits");
+  I8IE_REQUIRE((size_t)c.Npad * c.Kpad < ((size_t)1 << 32) - 4096, "mlin: offsets exceed 32 bits");
   I8IE_REQUIRE(c.Npad % kMlFeats == 0, "mlin: the weight panel must be padded to whole 128-feature tiles");
   MlinArgs a{};
   a.A = c.A; a.a_bytes = c.a_bytes; a.lda = (unsigned)c.lda; a.M = c.M;
@@ -335,19 +369,17 @@ int i8ie_mlin_launch(i8ie_ctx* ctx, const I8ieIgemmCall& c) {
   a.relu_lo = c.relu ? c.zp_out : 0;
   a.out = c.out; a.acc = c.acc;
   a.n_tiles = (c.N + kMlFeats - 1) / kMlFeats;
-  a.m_tiles = (c.M + kMlRows - 1) / kMlRows;
-  a.ahead = kMlAhead;  // (swept inside the AlexNet step at 1000 rows: 2 / 5 / 10 chunks 0.083 ms, 20: 0.087, 40: 0.092)
-  static bool raised[64] = {};
+  a.ahead = kMlAhead;
+  static int cus[64] = {};
   const int dev = ctx->device & 63;
-  if (!raised[dev]) {
-    I8IE_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMlLds));
-    raised[dev] = true;
+  if (cus[dev] == 0) {
+    hipDeviceProp_t prop;
+    I8IE_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int per = (a.n_tiles + 7) / 8;
-  const int grid = 8 * per * a.m_tiles;
-  const double ops = 2.0 * c.M * c.N * c.Ktrue, bytes = (double)c.M * c.Ktrue + (double)c.N * c.Ktrue + (double)c.M * c.N;
-  I8ieProfScope prof(ctx, "mlin_128x128", ops, bytes);
-  mlin_kernel<<<grid, 512, kMlLds, ctx->stream>>>(a);
-  I8IE_LAUNCH_CHECK();
-  return I8IE_OK;
+  // 64-row tiles when 128-row tiles give at most half the CUs a block (variant 84 / 85 force 64 / 128 rows)
+  const long blocks128 = (long)((c.M + 127) / 128) * a.n_tiles;
+  const bool rows64 = ctx->variant == 84 || (ctx->variant != 85 && blocks128 * 2 <= i8ie_cus(ctx, cus[dev]));
+  if (rows64) return mlin_launch_t<64>(ctx, a, c, "mlin_64x128");
+  return mlin_launch_t<128>(ctx, a, c, "mlin_128x128");
 }

@@ -59,13 +59,35 @@ def _run(gpu, c, relu, variant):
 def test_mlin_bit_exact(gpu, orc, mkn, relu):
     m, k, n = mkn
     c = synth.linear_case(orc, 900 + m + k + n, m, k, n)
-    (out, acc, _), names = _kernels_run(gpu, lambda: _run(gpu, c, relu, 0 if (m > 384 and n >= 2048) else 83))  # (83: below the automatic thresholds)
-    assert "mlin_128x128" in names, names
+    (out, acc, _), names = _kernels_run(gpu, lambda: _run(gpu, c, relu, 0 if n >= 2048 else 83))  # (83: below the automatic thresholds)
+    assert any(nm.startswith("mlin_") for nm in names), names
     want = orc.relu(c["out"], c["zp_out"]) if relu else c["out"]
     assert np.array_equal(acc, c["acc"]) and np.array_equal(out, want)
     (out2, acc2, _), names2 = _kernels_run(gpu, lambda: _run(gpu, c, relu, 11))
     assert not any(nm.startswith("mlin") for nm in names2), names2
     assert np.array_equal(out2, out) and np.array_equal(acc2, acc)
+
+
+@pytest.mark.parametrize("mkn", SHAPES)
+def test_mlin_both_row_tiles_bit_exact(gpu, orc, mkn):
+    """The 64-row and the 128-row block tile on every shape (variants 84 / 85; automatic: 64 rows when 128-row tiles would give at
+    most half the CUs a block, e.g. fc6 / fc7 at 500 rows)."""
+    m, k, n = mkn
+    c = synth.linear_case(orc, 900 + m + k + n, m, k, n)
+    want = orc.relu(c["out"], c["zp_out"])
+    for variant, name in ((84, "mlin_64x128"), (85, "mlin_128x128")):
+        (out, acc, _), names = _kernels_run(gpu, lambda: _run(gpu, c, True, variant))
+        assert name in names, names
+        assert np.array_equal(acc, c["acc"]) and np.array_equal(out, want), variant
+
+
+def test_mlin_picks_the_row_tile_by_block_count(gpu, orc):
+    c = synth.linear_case(orc, 5, 500, 1024, 4096)
+    (_, _, _), names = _kernels_run(gpu, lambda: _run(gpu, c, False, 0))
+    assert "mlin_64x128" in names, names
+    c = synth.linear_case(orc, 6, 1000, 1024, 4096)
+    (_, _, _), names = _kernels_run(gpu, lambda: _run(gpu, c, False, 0))
+    assert "mlin_128x128" in names, names
 
 
 def test_mlin_extreme_values(gpu, orc):
@@ -87,6 +109,6 @@ def test_mlin_extreme_values(gpu, orc):
                 abi.ck(lib.i8ie_ctx_set_option(gpu.h, 2, 0))
 
         (out, acc, _), names = _kernels_run(gpu, run)
-        assert "mlin_128x128" in names, names
+        assert any(nm.startswith("mlin_") for nm in names), names
         want, pre, _ = orc.linear(q_in, qw, qb, 0.02, zp_in, 0.001, 0.7, 128, want_acc=True)
         assert np.array_equal(acc, pre) and np.array_equal(out, want)
